@@ -1,0 +1,158 @@
+/*
+ * smk.h -- C ABI of the MI355X-native volume ray-marcher that takes over Simian's renderer slot.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  A
+ * gluvvPrimitive subclass (INTEGRATION.md shows it; a buildable mirror lives in
+ * simian-spacemonkey_amd/host/) calls these from init()/draw() instead of issuing OpenGL.
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference tree, zzmuxi/simian-spacemonkey).
+ *
+ * Conventions (VolumeRenderer.cpp:101-126, glUE.cpp:194-207): int returns are 0 = ok,
+ * non-zero = error, message via smk_last_error(); nothing throws.  Inputs are copied at the
+ * call (the reference renderers copy into texture memory at init(), NV20VolRen3D.cpp:1315-1330);
+ * the caller keeps ownership of every pointer it passes.  One context per GPU, not thread-safe
+ * (the reference is single-threaded GLUT).  There is NO CPU fallback: without a HIP device
+ * smk_create() fails.
+ */
+#ifndef SMK_H
+#define SMK_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smk_ctx smk_ctx;
+
+/* voxel storage handed over by the caller */
+typedef enum { SMK_U8 = 0, SMK_F32 = 1 } smk_dtype;
+
+/* gluvvDataMode, same order and meaning (gluvv.h:221-235) */
+typedef enum {
+  SMK_GDM_V1, SMK_GDM_V1G, SMK_GDM_V1GH, SMK_GDM_V2, SMK_GDM_V2G, SMK_GDM_V2GH, SMK_GDM_V3,
+  SMK_GDM_V3G, SMK_GDM_V4, SMK_GDM_VGH, SMK_GDM_VGH_VG, SMK_GDM_VGH_V, SMK_GDM_UNKNOWN
+} smk_datamode;
+
+/* shading: gluvvShade (gluvv.h:199-207) collapsed to what the two VGH renderers implement */
+typedef enum {
+  SMK_SHADE_NONE = 0,      /* gluvvShadeAmb / Faux: colour * alpha only                        */
+  SMK_SHADE_R8K_DIFF = 1,  /* R8kVolRen3D cube-map Phong, diffuse only (gluvvShadeDiff)         */
+  SMK_SHADE_R8K_DSPEC = 2, /* R8kVolRen3D diffuse + specular^30 (gluvvShadeDSpec) -- canonical  */
+  SMK_SHADE_NV20_DIFF = 3, /* NV20VolRen3D register-combiner Phong, diffuse                     */
+  SMK_SHADE_NV20_DSPEC = 4 /* NV20VolRen3D diffuse + specular^16                                */
+} smk_shade;
+
+/* Exactly the fields of `class Volume` a renderer reads (MetaVolume.h:18-61): one brick as
+ * produced by MetaVolume::brick (MetaVolume.cpp:1369-1452). */
+typedef struct {
+  int xiSize, yiSize, ziSize;   /* voxels                                                  */
+  float xfSize, yfSize, zfSize; /* extent in volume space                                  */
+  int xiPos, yiPos, ziPos;      /* voxel origin inside the whole volume                    */
+  float xfPos, yfPos, zfPos;    /* origin in volume space                                  */
+  const void *data;             /* currentData: [z][y][x][nelts], u8 or f32                */
+  const unsigned char *grad;    /* currentGrad: [z][y][x][3] scale-biased normals, or NULL */
+} smk_volume_desc;
+
+/* replaces `new VolumeRenderer(gluvv.mv,0)` / the renderer constructors (VolumeRenderable.cpp:66,
+ * gluvv.cpp:141-199).  device_ordinal >= 0.  *err (may be NULL) gets 0 or an error code. */
+smk_ctx *smk_create(int device_ordinal, int *err);
+void smk_destroy(smk_ctx *ctx);
+const char *smk_last_error(smk_ctx *ctx); /* ctx may be NULL: last smk_create failure */
+
+/* replaces VolumeRenderer::createVolume x2 (VolumeRenderer.cpp:101-212) and
+ * NV20VolRen3D/R8kVolRen3D::createBricks (NV20VolRen3D.cpp:1255-1369, R8kVolRen3D.cpp:1926-2055):
+ * copies the bricks of one MetaVolume into HBM.  Bricks must tile the volume (MetaVolume::brick
+ * output, or a single whole volume).  They are re-assembled into one dense volume with global
+ * voxel addressing, which removes the reference's seam artefacts. */
+int smk_upload_volume(smk_ctx *ctx, const smk_volume_desc *bricks, int n_bricks, int nelts,
+                      smk_dtype dtype, smk_datamode dmode);
+/* same, but data/grad are DEVICE pointers on this context's GPU (volumes produced on the GPU,
+ * e.g. by smk_synth_volume/smk_make_vgh_device; no PCIe copy) */
+int smk_upload_volume_device(smk_ctx *ctx, const smk_volume_desc *bricks, int n_bricks, int nelts,
+                             smk_dtype dtype, smk_datamode dmode);
+
+/* Sort-last sharding (no reference equivalent: the reference draws bricks serially on one GPU,
+ * NV20VolRen3D.cpp:190-231).  Must be called BEFORE smk_upload_volume: the context then keeps
+ * only its convex sub-box (+1 voxel halo) of the volume.  nranks in {1,2,4,8}: split x, then y,
+ * then z at the midpoint -- the MetaVolume::brick grid for a 2x2x2 bricking. */
+int smk_set_shard(smk_ctx *ctx, int rank, int nranks);
+/* front-to-back order of the ranks for the current camera (BSP rule per split axis) */
+int smk_shard_order(smk_ctx *ctx, int *order_out /* nranks */);
+
+/* replaces TLUT::loadTransferTableRGBA (TLUT.cpp:48-81): straight-colour float RGBA[size] as
+ * held in TLUT::_rgba (already opacity-corrected by TLUT::scaleAlpha, which the caller keeps
+ * doing exactly as VolumeRenderable::draw does, VolumeRenderable.cpp:50); premultiplied here. */
+int smk_set_tlut1d(smk_ctx *ctx, const float *rgba, int size);
+/* replaces NV20VolRen3D::loadDepTex x2 (NV20VolRen3D.cpp:1579-1622): deptex[sg][sv][RGBA8]
+ * (gluvv.volren.deptex) and the optional third-axis table deptex2 (gluvv.volren.deptex2). */
+int smk_set_tf2d(smk_ctx *ctx, const unsigned char *deptex, const unsigned char *deptex2_or_null,
+                 int sv, int sg);
+/* replaces TFWidgetRen::loadPtex for the dense table ptex[sh][sg][sv][RGBA8]
+ * (TFWidgetRen.cpp:779-845) */
+int smk_set_tf3d(smk_ctx *ctx, const unsigned char *ptex, int sv, int sg, int sh);
+
+/* replaces the glGetDoublev(GL_MODELVIEW_MATRIX) + glFrustum state a renderer reads
+ * (VolumeRenderable.cpp:40-49, gluvv.cpp:531-552): column-major modelview, frustum
+ * {left,right,bottom,top} at clip[0] (near), window size (gluvv.win). */
+int smk_set_camera(smk_ctx *ctx, const double modelview[16], const float frustum[4],
+                   const float clip[2], int width, int height);
+/* replaces R8kVolRen3D::loadCubeTex (R8kVolRen3D.cpp:2620-2679) / NV20VolRen3D::setupRegComb's
+ * host half (NV20VolRen3D.cpp:637-668): gluvv.light.pos, gluvv.env.eye/at, gluvv.rinfo.xform,
+ * gluvv.light.intens, gluvv.light.amb (amb is only consumed by the shadow passes; stored) */
+int smk_set_shading(smk_ctx *ctx, smk_shade mode, const float light_pos[3], const float eye[3],
+                    const float at[3], const float xform[16], float intens, float amb);
+/* gluvv.volren.sampleRate / gamma / scaleAlphas (NV20VolRen3D.cpp:87-122).  steps > 0 fixes the
+ * plane count instead (dis = view-depth extent / steps).  With scale_alphas the 2-D TF alpha is
+ * corrected as copyScale does (NV20VolRen3D.cpp:1645-1660) with rate/gamma. */
+int smk_set_sampling(smk_ctx *ctx, float sample_rate, int steps, float gamma, int scale_alphas);
+/* replaces R8kVolRen3D_cpy::createNoiseTex + gluvv.pert (R8kVolRen3D_cpy.cpp:2392-2480,
+ * 1590-1595): n^3 RGBA8 noise (GL_REPEAT), weights/scales of the two live octaves. noise NULL
+ * or all weights 0 turns perturbation off. */
+int smk_set_perturb(smk_ctx *ctx, const unsigned char *noise_rgba, int n, const float w[4],
+                    const float s[4]);
+
+/* replaces gluvvPrimitive::draw() -> renderVolume (VolumeRenderer.cpp:280-328,
+ * NV20VolRen3D.cpp:87-185): one frame.  rgba_out: [height][width][4] float, premultiplied,
+ * row 0 = bottom (GL window order).  depth_out (may be NULL): view-space depth of the first
+ * contributing sample, +inf where none. */
+int smk_render(smk_ctx *ctx, float *rgba_out, float *depth_out);
+/* same with DEVICE output pointers; asynchronous on `stream` (a hipStream_t, NULL = default) */
+int smk_render_device(smk_ctx *ctx, void *d_rgba, void *d_depth, void *stream);
+
+/* sort-last merge: out = layer[order[0]] over layer[order[1]] over ...; layers are
+ * premultiplied RGBA tiles of npix pixels, DEVICE pointers, layer l at layers + l*npix*4 floats. */
+int smk_composite_over_device(smk_ctx *ctx, const void *d_layers, int nlayers, const int *order,
+                              int npix, void *d_out, void *stream);
+
+/* data prep on the GPU (genVGH/main.cpp:56-182, VectorMath.h:874-899,
+ * 1133-1148, 1217-1281).  All pointers are DEVICE pointers.
+ *   scalar  [z][y][x] u8 or f32      -> vgh_u8 [z][y][x][3] (quantised as makeVGH) and/or
+ *                                       vgh_f32 [z][y][x][3] in [0,1] (unquantised variant)
+ *   vgh_u8                           -> normals [z][y][x][3] (derivative3DVGH+[blurV3D]+scalebiasN) */
+int smk_make_vgh_device(smk_ctx *ctx, const void *d_scalar, smk_dtype dtype, int sx, int sy,
+                        int sz, int compat, void *d_vgh_u8_or_null, void *d_vgh_f32_or_null);
+int smk_normals_vgh_device(smk_ctx *ctx, const void *d_vgh_u8, int nelts, int sx, int sy, int sz,
+                           int blur, void *d_normals);
+/* synthetic scalar test volume generated on the GPU (bench input; analytic, seed-stable):
+ * kind 0 = noisy concentric shells (u8) */
+int smk_synth_volume_device(smk_ctx *ctx, int kind, unsigned seed, int sx, int sy, int sz,
+                            void *d_scalar_u8);
+
+/* introspection used by tests and bench (no reference equivalent) */
+typedef struct {
+  float pxs, pxl, pys, pyl;
+  float Ac[3], Ax[3], Ay[3], Bc[3], Bx[3], By[3];
+  int nplanes;
+  float tau0, dtau, zmin, zmax, dis;
+} smk_raycoef;
+int smk_get_raycoef(smk_ctx *ctx, smk_raycoef *out);
+/* "kernel": 0 auto, 1 gather (generic), 2 slab-staged (LDS).  "slab_T": slices per slab. */
+int smk_set_option(smk_ctx *ctx, const char *key, int value);
+/* last frame: which kernel ran (1/2), its HIP-event time in ms, algorithmic bytes */
+int smk_last_frame_info(smk_ctx *ctx, int *kernel, float *ms, double *alg_bytes);
+/* effective 2-D TF after opacity correction, as uploaded (sg*sv*4 bytes) */
+int smk_get_tf2d_effective(smk_ctx *ctx, unsigned char *out, float *rate_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,241 @@
+// smk_device.h -- per-sample device functions shared by the render kernels (gfx950 only).
+//
+// Arithmetic contract (DESIGN.md "sample placement"): everything that decides WHERE a sample
+// is and WHICH texels it touches is an explicit fp32 fma chain (compile with
+// -ffp-contract=off); the same chains, written independently, live in the CPU checker.
+//
+// Semantics per sample (reference file:line, relative to the reference tree):
+//   trilinear, clamp-to-edge ............ NV20VolRen3D.cpp:1379-1383, VolumeRenderer.cpp:410-418
+//   1-D colour table (post-filter) ...... VolumeRenderer.cpp:576-587, TLUT.cpp:65-80
+//   2-D TF (V,G) x third axis (H,4th) ... NV20VolRen3D.cpp:544-596, 810-838
+//   dense 3-D TF ........................ TFWidgetRen.cpp:779-845
+//   Phong, R8k cube map + shader ........ R8kVolRen3D.cpp:2620-2679, 2831-2977
+//   Phong, NV20 combiners ............... NV20VolRen3D.cpp:634-806
+//   front-to-back blend ................. R8kVolRen3D.cpp:1441-1449
+#pragma once
+#include "smk_internal.h"
+
+#define SMK_INV255 (1.0f / 255.0f)
+
+__device__ __forceinline__ float smk_lerp(float a, float b, float f) { return __fmaf_rn(f, b - a, a); }
+__device__ __forceinline__ float smk_sat(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+// GL_LINEAR + clamp-to-edge along one axis, x in texel units
+__device__ __forceinline__ void smk_lin_clamp(float x, int n, int &i0, int &i1, float &f) {
+  float xc = fminf(fmaxf(x, 0.0f), (float)(n - 1));
+  int i = (int)xc;
+  int imax = n >= 2 ? n - 2 : 0;
+  i = min(i, imax);
+  i0 = i;
+  i1 = min(i + 1, n - 1);
+  f = xc - (float)i;
+}
+
+// GL_LINEAR + GL_REPEAT
+__device__ __forceinline__ void smk_lin_repeat(float x, int n, int &i0, int &i1, float &f) {
+  float fl = floorf(x);
+  f = x - fl;
+  int i = (int)fl % n;
+  if (i < 0) i += n;
+  i0 = i;
+  i1 = (i + 1) % n;
+}
+
+__device__ __forceinline__ float smk_ub(uint32_t v, int k) { return (float)((v >> (8 * k)) & 0xffu); }
+
+// one voxel corner: 4 channels (raw: u8 as 0..255 floats, f32 as is) + packed normal bits
+struct SmkCorner {
+  float c0, c1, c2, c3;
+  uint32_t nb;
+};
+
+template <int DT>
+__device__ __forceinline__ SmkCorner smk_load_corner(const RenderParams &P, size_t idx) {
+  SmkCorner k;
+  if (DT == 0) {
+    uint2 v = ((const uint2 *)P.vox)[idx];
+    k.c0 = smk_ub(v.x, 0);
+    k.c1 = smk_ub(v.x, 1);
+    k.c2 = smk_ub(v.x, 2);
+    k.c3 = smk_ub(v.x, 3);
+    k.nb = v.y;
+  } else {
+    float4 v = ((const float4 *)P.vox)[idx];
+    k.c0 = v.x;
+    k.c1 = v.y;
+    k.c2 = v.z;
+    if (P.n_in_w) {
+      k.c3 = 0.0f;
+      k.nb = __float_as_uint(v.w);
+    } else {
+      k.c3 = v.w;
+      k.nb = P.nrm ? P.nrm[idx] : 0x808080u;
+    }
+  }
+  return k;
+}
+
+#define SMK_TRI(field)                                                                  \
+  smk_lerp(smk_lerp(smk_lerp(k000.field, k100.field, fx), smk_lerp(k010.field, k110.field, fx), fy), \
+           smk_lerp(smk_lerp(k001.field, k101.field, fx), smk_lerp(k011.field, k111.field, fx), fy), fz)
+
+// bilinear RGBA8 lookup, s,t in [0,1]
+__device__ __forceinline__ float4 smk_tex2d(const uint32_t *tex, int ss, int st, float s, float t) {
+  int s0, s1, t0, t1;
+  float fs, ft;
+  smk_lin_clamp(__fmaf_rn(s, (float)ss, -0.5f), ss, s0, s1, fs);
+  smk_lin_clamp(__fmaf_rn(t, (float)st, -0.5f), st, t0, t1, ft);
+  uint32_t a = tex[t0 * ss + s0], b = tex[t0 * ss + s1], c = tex[t1 * ss + s0], d = tex[t1 * ss + s1];
+  float4 o;
+  o.x = smk_lerp(smk_lerp(smk_ub(a, 0), smk_ub(b, 0), fs), smk_lerp(smk_ub(c, 0), smk_ub(d, 0), fs), ft) * SMK_INV255;
+  o.y = smk_lerp(smk_lerp(smk_ub(a, 1), smk_ub(b, 1), fs), smk_lerp(smk_ub(c, 1), smk_ub(d, 1), fs), ft) * SMK_INV255;
+  o.z = smk_lerp(smk_lerp(smk_ub(a, 2), smk_ub(b, 2), fs), smk_lerp(smk_ub(c, 2), smk_ub(d, 2), fs), ft) * SMK_INV255;
+  o.w = smk_lerp(smk_lerp(smk_ub(a, 3), smk_ub(b, 3), fs), smk_lerp(smk_ub(c, 3), smk_ub(d, 3), fs), ft) * SMK_INV255;
+  return o;
+}
+
+__device__ __forceinline__ float smk_tex2d_alpha(const uint32_t *tex, int ss, int st, float s, float t) {
+  int s0, s1, t0, t1;
+  float fs, ft;
+  smk_lin_clamp(__fmaf_rn(s, (float)ss, -0.5f), ss, s0, s1, fs);
+  smk_lin_clamp(__fmaf_rn(t, (float)st, -0.5f), st, t0, t1, ft);
+  uint32_t a = tex[t0 * ss + s0], b = tex[t0 * ss + s1], c = tex[t1 * ss + s0], d = tex[t1 * ss + s1];
+  return smk_lerp(smk_lerp(smk_ub(a, 3), smk_ub(b, 3), fs), smk_lerp(smk_ub(c, 3), smk_ub(d, 3), fs), ft) * SMK_INV255;
+}
+
+__device__ __forceinline__ float4 smk_tex3d(const uint32_t *tex, int ss, int st, int sr, float s, float t, float r) {
+  int s0, s1, t0, t1, r0, r1;
+  float fs, ft, fr;
+  smk_lin_clamp(__fmaf_rn(s, (float)ss, -0.5f), ss, s0, s1, fs);
+  smk_lin_clamp(__fmaf_rn(t, (float)st, -0.5f), st, t0, t1, ft);
+  smk_lin_clamp(__fmaf_rn(r, (float)sr, -0.5f), sr, r0, r1, fr);
+  uint32_t q[8];
+  q[0] = tex[(r0 * st + t0) * ss + s0];
+  q[1] = tex[(r0 * st + t0) * ss + s1];
+  q[2] = tex[(r0 * st + t1) * ss + s0];
+  q[3] = tex[(r0 * st + t1) * ss + s1];
+  q[4] = tex[(r1 * st + t0) * ss + s0];
+  q[5] = tex[(r1 * st + t0) * ss + s1];
+  q[6] = tex[(r1 * st + t1) * ss + s0];
+  q[7] = tex[(r1 * st + t1) * ss + s1];
+  float o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    o[e] = smk_lerp(smk_lerp(smk_lerp(smk_ub(q[0], e), smk_ub(q[1], e), fs), smk_lerp(smk_ub(q[2], e), smk_ub(q[3], e), fs), ft),
+                    smk_lerp(smk_lerp(smk_ub(q[4], e), smk_ub(q[5], e), fs), smk_lerp(smk_ub(q[6], e), smk_ub(q[7], e), fs), ft), fr) *
+           SMK_INV255;
+  return make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// wrap-around trilinear fetch of the noise volume, rgb only
+__device__ __forceinline__ void smk_noise(const RenderParams &P, float s, float t, float r, float o[3]) {
+  int n = P.nn, s0, s1, t0, t1, r0, r1;
+  float fs, ft, fr;
+  smk_lin_repeat(__fmaf_rn(s, (float)n, -0.5f), n, s0, s1, fs);
+  smk_lin_repeat(__fmaf_rn(t, (float)n, -0.5f), n, t0, t1, ft);
+  smk_lin_repeat(__fmaf_rn(r, (float)n, -0.5f), n, r0, r1, fr);
+  const uint32_t *tex = P.noise;
+  uint32_t q[8];
+  q[0] = tex[(r0 * n + t0) * n + s0];
+  q[1] = tex[(r0 * n + t0) * n + s1];
+  q[2] = tex[(r0 * n + t1) * n + s0];
+  q[3] = tex[(r0 * n + t1) * n + s1];
+  q[4] = tex[(r1 * n + t0) * n + s0];
+  q[5] = tex[(r1 * n + t0) * n + s1];
+  q[6] = tex[(r1 * n + t1) * n + s0];
+  q[7] = tex[(r1 * n + t1) * n + s1];
+#pragma unroll
+  for (int e = 0; e < 3; ++e)
+    o[e] = smk_lerp(smk_lerp(smk_lerp(smk_ub(q[0], e), smk_ub(q[1], e), fs), smk_lerp(smk_ub(q[2], e), smk_ub(q[3], e), fs), ft),
+                    smk_lerp(smk_lerp(smk_ub(q[4], e), smk_ub(q[5], e), fs), smk_lerp(smk_ub(q[6], e), smk_ub(q[7], e), fs), ft), fr) *
+           SMK_INV255;
+}
+
+__device__ __forceinline__ float smk_pow30(float x) {
+  float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8;
+  return ((x16 * x8) * x4) * x2;
+}
+
+// classification of interpolated channels -> straight colour + alpha; returns false if alpha==0
+template <int DT, int TF>
+__device__ __forceinline__ bool smk_classify(const RenderParams &P, float ch0, float ch1, float ch2, float ch3,
+                                             float4 &col) {
+  if (TF == 0) {
+    int idx = (int)__fmaf_rn(ch0, (float)(P.tlut_size - 1), 0.5f);
+    idx = max(0, min(idx, P.tlut_size - 1));
+    col = P.tlut[idx];  // already premultiplied
+    return col.w != 0.0f;
+  } else if (TF == 1) {
+    col = smk_tex2d(P.tf_vg, P.sv, P.sg, ch0, ch1);
+    if (P.third_axis) col.w *= smk_tex2d_alpha(P.tf_h, P.sv, P.sg, ch2, ch3);
+  } else {
+    col = smk_tex3d(P.tf3d, P.s3v, P.s3g, P.s3h, ch0, ch1, ch2);
+  }
+  col.w = smk_sat(col.w);
+  return col.w != 0.0f;
+}
+
+// SH: 0 none, 1 R8k, 2 NV20.  n = decoded interpolated normal, g = second data channel.
+// in: straight colour col (col.w = alpha); out: premultiplied src
+template <int SH>
+__device__ __forceinline__ float4 smk_shade_sample(const RenderParams &P, float4 col, float n0, float n1, float n2, float g) {
+  float a = col.w;
+  float c[3] = {col.x, col.y, col.z};
+  if (SH == 1) {
+    float w0 = __fmaf_rn(P.R[0], n0, __fmaf_rn(P.R[1], n1, P.R[2] * n2));
+    float w1 = __fmaf_rn(P.R[3], n0, __fmaf_rn(P.R[4], n1, P.R[5] * n2));
+    float w2 = __fmaf_rn(P.R[6], n0, __fmaf_rn(P.R[7], n1, P.R[8] * n2));
+    float l2 = __fmaf_rn(w0, w0, __fmaf_rn(w1, w1, w2 * w2));
+    float il = l2 > 0.0f ? rsqrtf(l2) : 0.0f;  // the cube map is addressed by direction
+    w0 *= il;
+    w1 *= il;
+    w2 *= il;
+    float dl = fabsf(__fmaf_rn(P.L[0], w0, __fmaf_rn(P.L[1], w1, P.L[2] * w2)));
+    float dh = fabsf(__fmaf_rn(P.Hv[0], w0, __fmaf_rn(P.Hv[1], w1, P.Hv[2] * w2)));
+    float kd = smk_sat(fmaxf(smk_sat(dl), 0.2f)) * P.intens;
+    float ks = P.use_spec ? smk_sat(smk_pow30(smk_sat(dh))) * P.intens : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float shaded = __fmaf_rn(c[k], kd, ks);
+      c[k] = __fmaf_rn(g, shaded - c[k], c[k]);
+    }
+  } else if (SH == 2) {
+    float dl = fabsf(__fmaf_rn(P.L[0], n0, __fmaf_rn(P.L[1], n1, P.L[2] * n2)));
+    float dh = __fmaf_rn(P.Hv[0], n0, __fmaf_rn(P.Hv[1], n1, P.Hv[2] * n2));
+    float s2 = smk_sat(dh * dh), s4 = s2 * s2, s8 = s4 * s4, s16 = s8 * s8;
+    float spec = P.use_spec ? s16 * P.intens * a : 0.0f;
+    float ia = P.intens * a, aa = 0.3f * a;
+    float4 o;
+    float r[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float cc = smk_sat(__fmaf_rn(c[k] * smk_sat(dl), ia, c[k] * aa));
+      r[k] = smk_sat(__fmaf_rn(spec, 1.0f - cc, cc));
+    }
+    o.x = r[0];
+    o.y = r[1];
+    o.z = r[2];
+    o.w = a;
+    return o;
+  }
+  return make_float4(smk_sat(c[0] * a), smk_sat(c[1] * a), smk_sat(c[2] * a), a);
+}
+
+__device__ __forceinline__ float smk_nrm(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t e, uint32_t f,
+                                         uint32_t g, uint32_t h, int k, float fx, float fy, float fz) {
+  float v = smk_lerp(smk_lerp(smk_lerp(smk_ub(a, k), smk_ub(b, k), fx), smk_lerp(smk_ub(c, k), smk_ub(d, k), fx), fy),
+                     smk_lerp(smk_lerp(smk_ub(e, k), smk_ub(f, k), fx), smk_lerp(smk_ub(g, k), smk_ub(h, k), fx), fy), fz);
+  return __fmaf_rn(v, 2.0f * SMK_INV255, -1.0f);
+}
+
+// XCD-aware tile mapping: blocks are dealt round-robin over the 8 XCDs (bid % 8 shares an
+// XCD), so give each XCD one contiguous run of tiles -- neighbouring image tiles, which walk
+// neighbouring voxels, then share an L2.  Speed only; any placement is correct.
+__device__ __forceinline__ bool smk_tile_of_block(const RenderParams &P, int bid, int &tx, int &ty) {
+  int xcd = bid & 7, k = bid >> 3;
+  int tile = xcd * P.tiles_per_xcd + k;
+  if (k >= P.tiles_per_xcd || tile >= P.ntx * P.nty) return false;
+  ty = tile / P.ntx;
+  tx = tile - ty * P.ntx;
+  return true;
+}

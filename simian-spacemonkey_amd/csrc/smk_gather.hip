@@ -1,0 +1,160 @@
+// smk_gather.hip -- kernel G: the generic ray-marcher.  One lane = one ray; voxel corners,
+// transfer-function texels and noise texels are gathered straight from HBM/L2 (no staging).
+// It covers every mode of the C ABI (u8/f32, 1-/2-/3-D classification, both Phong variants,
+// perturbation, sharded regions) and is the fallback the slab-staged kernel (smk_slab.hip)
+// defers to.  Replaces the per-slice polygon loop + fragment pipeline of
+// VolumeRenderer::render3DVA (VolumeRenderer.cpp:507-741) / NV20VolRen3D::render3DVA (:852-1083).
+//
+// Wavefront packing: a 256-thread workgroup is a 16x16 pixel tile, each 64-lane wave an 8x8
+// sub-tile, so the 64 rays of a wave stay spatially compact (their corner fetches fall in few
+// cache lines) and walk the volume together.
+#include "smk_device.h"
+
+template <int DT, int TF, int SH>
+__global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
+  int tx, ty;
+  if (!smk_tile_of_block(P, blockIdx.x, tx, ty)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = tx * 16 + (wave & 1) * 8 + (lane & 7);
+  const int j = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+  if (i >= P.W || j >= P.H) return;
+
+  const smk_raycoef &rc = P.rc;
+  const float px = __fmaf_rn((float)i + 0.5f, rc.pxs, rc.pxl);
+  const float py = __fmaf_rn((float)j + 0.5f, rc.pys, rc.pyl);
+  float A[3], B[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    A[a] = __fmaf_rn(px, rc.Ax[a], __fmaf_rn(py, rc.Ay[a], rc.Ac[a]));
+    B[a] = __fmaf_rn(px, rc.Bx[a], __fmaf_rn(py, rc.By[a], rc.Bc[a]));
+  }
+
+  // conservative plane range [m0,m1] from a slab test (+-2 planes of slack); the exact
+  // per-sample inside test below is what decides membership
+  float tenter = 0.0f, texit = (float)(rc.nplanes - 1);
+  bool empty = rc.nplanes <= 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (fabsf(B[a]) > 1e-20f) {
+      float inv = 1.0f / B[a];
+      float t1 = (P.lo[a] - A[a]) * inv, t2 = (P.hi[a] - A[a]) * inv;
+      tenter = fmaxf(tenter, fminf(t1, t2) - 2.0f);
+      texit = fminf(texit, fmaxf(t1, t2) + 2.0f);
+    } else if (!(A[a] >= P.lo[a] && A[a] <= P.hi[a])) {
+      empty = true;
+    }
+  }
+  int m0 = (int)floorf(fmaxf(tenter, 0.0f));
+  int m1 = (int)ceilf(fminf(texit, (float)(rc.nplanes - 1)));
+  if (empty || !(tenter <= texit)) m1 = m0 - 1;
+
+  float C0 = 0.f, C1 = 0.f, C2 = 0.f, C3 = 0.f;
+  float first = __int_as_float(0x7f800000);
+  const int Dx = P.D[0], Dy = P.D[1];
+
+  for (int m = m0; m <= m1; ++m) {
+    float p0 = __fmaf_rn((float)m, B[0], A[0]);
+    float p1 = __fmaf_rn((float)m, B[1], A[1]);
+    float p2 = __fmaf_rn((float)m, B[2], A[2]);
+    bool in = (p0 >= P.lo[0] && (p0 < P.hi[0] || (P.top[0] && p0 <= P.hi[0]))) &&
+              (p1 >= P.lo[1] && (p1 < P.hi[1] || (P.top[1] && p1 <= P.hi[1]))) &&
+              (p2 >= P.lo[2] && (p2 < P.hi[2] || (P.top[2] && p2 <= P.hi[2])));
+    if (!in) continue;
+
+    if (P.pert_on) {
+      // tc' = tc + sum w_m (noise(tc s_m) - .5)   (R8kVolRen3D_cpy.cpp:1590-1595, 3462-3490)
+      float t0 = (p0 + 0.5f) * P.invN[0], t1 = (p1 + 0.5f) * P.invN[1], t2 = (p2 + 0.5f) * P.invN[2];
+      float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (P.pw[q] == 0.0f) continue;
+        float nz[3];
+        smk_noise(P, t0 * P.ps[q], t1 * P.ps[q], t2 * P.ps[q], nz);
+        o0 = __fmaf_rn(P.pw[q], nz[0] - 0.5f, o0);
+        o1 = __fmaf_rn(P.pw[q], nz[1] - 0.5f, o1);
+        o2 = __fmaf_rn(P.pw[q], nz[2] - 0.5f, o2);
+      }
+      p0 = __fmaf_rn(t0 + o0, (float)P.N[0], -0.5f);
+      p1 = __fmaf_rn(t1 + o1, (float)P.N[1], -0.5f);
+      p2 = __fmaf_rn(t2 + o2, (float)P.N[2], -0.5f);
+    }
+
+    int x0, x1, y0, y1, z0, z1;
+    float fx, fy, fz;
+    smk_lin_clamp(p0, P.N[0], x0, x1, fx);
+    smk_lin_clamp(p1, P.N[1], y0, y1, fy);
+    smk_lin_clamp(p2, P.N[2], z0, z1, fz);
+    // stored box is region + halo; a perturbed fetch may leave it: clamp for memory safety
+    // (smk_set_perturb refuses configurations whose halo is too small, so this never alters
+    // a result)
+    x0 = min(max(x0 - P.O[0], 0), P.D[0] - 1);
+    x1 = min(max(x1 - P.O[0], 0), P.D[0] - 1);
+    y0 = min(max(y0 - P.O[1], 0), P.D[1] - 1);
+    y1 = min(max(y1 - P.O[1], 0), P.D[1] - 1);
+    z0 = min(max(z0 - P.O[2], 0), P.D[2] - 1);
+    z1 = min(max(z1 - P.O[2], 0), P.D[2] - 1);
+    size_t r00 = ((size_t)z0 * Dy + y0) * Dx, r10 = ((size_t)z0 * Dy + y1) * Dx;
+    size_t r01 = ((size_t)z1 * Dy + y0) * Dx, r11 = ((size_t)z1 * Dy + y1) * Dx;
+    SmkCorner k000 = smk_load_corner<DT>(P, r00 + x0), k100 = smk_load_corner<DT>(P, r00 + x1);
+    SmkCorner k010 = smk_load_corner<DT>(P, r10 + x0), k110 = smk_load_corner<DT>(P, r10 + x1);
+    SmkCorner k001 = smk_load_corner<DT>(P, r01 + x0), k101 = smk_load_corner<DT>(P, r01 + x1);
+    SmkCorner k011 = smk_load_corner<DT>(P, r11 + x0), k111 = smk_load_corner<DT>(P, r11 + x1);
+
+    const float sc = DT == 0 ? SMK_INV255 : 1.0f;
+    float ch0 = SMK_TRI(c0), ch1 = 0.f, ch2 = 0.f, ch3 = 0.f;
+    if (DT == 0) ch0 *= sc;
+    if (TF != 0 || SH != 0) {
+      ch1 = SMK_TRI(c1);
+      if (DT == 0) ch1 *= sc;
+    }
+    if (TF == 2 || (TF == 1 && P.third_axis)) {
+      ch2 = SMK_TRI(c2);
+      if (DT == 0) ch2 *= sc;
+      if (P.nelts == 4) {
+        ch3 = SMK_TRI(c3);
+        if (DT == 0) ch3 *= sc;
+      }
+    }
+
+    float4 col;
+    if (!smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col)) continue;
+
+    float4 src;
+    if (TF == 0) {
+      src = col;
+    } else if (SH == 0) {
+      src = smk_shade_sample<0>(P, col, 0.f, 0.f, 0.f, 0.f);
+    } else {
+      float n0 = smk_nrm(k000.nb, k100.nb, k010.nb, k110.nb, k001.nb, k101.nb, k011.nb, k111.nb, 0, fx, fy, fz);
+      float n1 = smk_nrm(k000.nb, k100.nb, k010.nb, k110.nb, k001.nb, k101.nb, k011.nb, k111.nb, 1, fx, fy, fz);
+      float n2 = smk_nrm(k000.nb, k100.nb, k010.nb, k110.nb, k001.nb, k101.nb, k011.nb, k111.nb, 2, fx, fy, fz);
+      src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1);
+    }
+    // C += (1-A) src   (GL_ONE_MINUS_DST_ALPHA, GL_ONE)
+    float w = 1.0f - C3;
+    if (first == __int_as_float(0x7f800000)) first = __fmaf_rn((float)m, rc.dtau, rc.tau0) * P.znear;
+    C0 = __fmaf_rn(w, src.x, C0);
+    C1 = __fmaf_rn(w, src.y, C1);
+    C2 = __fmaf_rn(w, src.z, C2);
+    C3 = __fmaf_rn(w, src.w, C3);
+  }
+  size_t o = (size_t)j * P.W + i;
+  P.out[o] = make_float4(C0, C1, C2, C3);
+  if (P.depth) P.depth[o] = first;
+}
+
+template <int DT, int TF, int SH>
+static hipError_t launch(const RenderParams &P, hipStream_t s) {
+  dim3 grid(8 * P.tiles_per_xcd), block(256);
+  hipLaunchKernelGGL((smk_k_gather<DT, TF, SH>), grid, block, 0, s, P);
+  return hipGetLastError();
+}
+
+hipError_t smk_launch_gather(const RenderParams &P, int dtype, int tf_mode, int shade_kind, hipStream_t s) {
+#define CASE(D, T, S) \
+  if (dtype == D && tf_mode == T && shade_kind == S) return launch<D, T, S>(P, s);
+  CASE(0, 0, 0) CASE(0, 1, 0) CASE(0, 1, 1) CASE(0, 1, 2) CASE(0, 2, 0) CASE(0, 2, 1) CASE(0, 2, 2)
+  CASE(1, 0, 0) CASE(1, 1, 0) CASE(1, 1, 1) CASE(1, 1, 2) CASE(1, 2, 0) CASE(1, 2, 1) CASE(1, 2, 2)
+#undef CASE
+  return hipErrorInvalidValue;
+}

@@ -1,0 +1,124 @@
+// smk_internal.h -- context and kernel-parameter structures of the HIP ray-marcher.
+// Product code: never includes anything from oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/smk.h"
+
+#define SMK_MAX_RANKS 8
+
+// Everything a render kernel needs, passed by value as the kernarg (wave-uniform => SGPRs).
+struct RenderParams {
+  // ---- volume, packed layout (DESIGN.md "HBM layout")
+  //   u8 : uint2  {c0|c1<<8|c2<<16|c3<<24, n0|n1<<8|n2<<16}                 8 B/voxel
+  //   f32: float4 {c0,c1,c2, c3 or normal bits}                            16 B/voxel
+  const void *vox;
+  const uint32_t *nrm;  // separate packed normals (only f32 with 4 channels), else null
+  int N[3];             // whole-volume dims
+  int O[3];             // global index of stored voxel (0,0,0)
+  int D[3];             // stored dims (region + halo)
+  float lo[3], hi[3];   // region in voxel coordinates: [g0-.5, g1-.5)
+  int top[3];           // region touches the volume's top face on this axis (inclusive)
+  float invN[3];
+  int nelts;
+  int n_in_w;  // f32: normal bits live in .w
+  // ---- classification
+  const float4 *tlut;  // premultiplied (r*a,g*a,b*a,a)
+  int tlut_size;
+  const uint32_t *tf_vg;  // [sg][sv] RGBA8
+  const uint32_t *tf_h;   // [sg][sv] RGBA8 (alpha used) or null
+  int sv, sg, third_axis;
+  const uint32_t *tf3d;  // [s3h][s3g][s3v]
+  int s3v, s3g, s3h;
+  // ---- camera / sample placement
+  smk_raycoef rc;
+  int W, H;
+  float znear;
+  // ---- shading
+  int use_spec;
+  float L[3], Hv[3];
+  float R[9];  // rows of rinfo.xform's rotation: Nw = R * n
+  float intens;
+  // ---- perturbation
+  const uint32_t *noise;  // [nn][nn][nn] RGBA8
+  int nn, pert_on;
+  float pw[2], ps[2];
+  // ---- output
+  float4 *out;
+  float *depth;
+  // ---- tile mapping
+  int ntx, nty, tiles_per_xcd;
+};
+
+struct smk_ctx {
+  int device = 0;
+  std::string err;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+  // volume
+  bool have_volume = false;
+  int dtype = 0, nelts = 0, dmode = 0;
+  int N[3] = {0, 0, 0};
+  float fsize[3] = {1, 1, 1};
+  int g0[3] = {0, 0, 0}, g1[3] = {0, 0, 0};  // this context's region
+  int O[3] = {0, 0, 0}, D[3] = {0, 0, 0};
+  int halo = 1;
+  void *d_vox = nullptr;
+  uint32_t *d_nrm = nullptr;
+  bool have_normals = false;
+  size_t vox_bytes = 0;
+
+  // sharding
+  int rank = 0, nranks = 1;
+
+  // classification
+  int tf_mode = -1;  // 0 1-D, 1 2-D, 2 3-D
+  float4 *d_tlut = nullptr;
+  int tlut_size = 0;
+  std::vector<unsigned char> h_tf_vg, h_tf_h, h_tf_eff;
+  uint32_t *d_tf_vg = nullptr, *d_tf_h = nullptr, *d_tf3d = nullptr;
+  int sv = 0, sg = 0, s3v = 0, s3g = 0, s3h = 0;
+  bool tf_dirty = true;
+  float tf_rate_applied = -1.f;
+
+  // camera
+  bool have_camera = false;
+  double mv[16];
+  float frustum[4], clip[2];
+  int W = 0, H = 0;
+
+  // sampling
+  float sample_rate = 2.5f, gamma = 1.f;
+  int steps = 0, scale_alphas = 1;
+
+  // shading
+  int shade = 0;
+  float light_pos[3] = {0, 0, -5}, eye[3] = {0, 0, -7}, at[3] = {0, 0, 0};
+  float xform[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  float intens = .75f, amb = .05f;
+
+  // perturbation
+  uint32_t *d_noise = nullptr;
+  int nn = 0;
+  float pw[4] = {0, 0, 0, 0}, ps[4] = {0, 0, 0, 0};
+
+  // scratch output for host-pointer renders
+  float4 *d_out = nullptr;
+  float *d_depth = nullptr;
+  size_t out_cap = 0;
+
+  // options / stats
+  int opt_kernel = 0, opt_slab_T = 0, opt_tf_raw = 0;
+  int last_kernel = 0;
+  float last_ms = 0;
+  double last_alg_bytes = 0;
+};
+
+// launchers (one translation unit per kernel family)
+hipError_t smk_launch_gather(const RenderParams &P, int dtype, int tf_mode, int shade_kind,
+                             hipStream_t s);
