@@ -1,0 +1,320 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the volume ray-march hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1: run directly)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Metric (BASELINE.json): Msamples/s (+ fps) of one frame of the 512^3 VGH volume at
+1024^2 x 512 planes: config 3 -- f32 VGH, 2-D LevWidget transfer function, gradient Phong.
+A "step" is one frame; inputs are synthetic and already resident in HBM when the timed region
+starts.  N > 1 is sort-last: the volume is sharded by brick region (strong scaling), each rank
+ray-marches the full viewport against its shard and the frames are merged by one RCCL
+all-to-all + ordered "over" + gather; that merge is inside the timed region.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (the ray-marcher) vs the HBM roofline, HIP-event timed in here
+  cpu_baseline  the CPU checker (oracle/, kind "port") timed on this box's host cores on a
+                bounded band of rows of the same frame (rank 0, N=1 only)
+  north_star    same kernel on the 1024^3 f32 VGH volume (config 4's single-GPU case), the
+                case BASELINE.json's >= 60 % HBM-roofline target is quoted on (N=1 only)
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, Chip-level parameters)
+
+
+def load_package():
+    name = "simian_spacemonkey_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    d = os.path.join(ROOT, "simian-spacemonkey_amd")
+    spec = importlib.util.spec_from_file_location(name, os.path.join(d, "__init__.py"),
+                                                  submodule_search_locations=[d])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# --------------------------------------------------------------------------- camera (no oracle)
+
+def rotation(axis, deg):
+    a = np.asarray(axis, np.float64)
+    a /= np.linalg.norm(a)
+    t = np.deg2rad(deg)
+    c, s = np.cos(t), np.sin(t)
+    x, y, z = a
+    R = np.array([[c + x * x * (1 - c), x * y * (1 - c) - z * s, x * z * (1 - c) + y * s],
+                  [y * x * (1 - c) + z * s, c + y * y * (1 - c), y * z * (1 - c) - x * s],
+                  [z * x * (1 - c) - y * s, z * y * (1 - c) + x * s, c + z * z * (1 - c)]])
+    M = np.eye(4)
+    M[:3, :3] = R
+    return M
+
+
+def look_at(eye, at, up):
+    eye, at, up = (np.asarray(v, np.float64) for v in (eye, at, up))
+    f = at - eye
+    f /= np.linalg.norm(f)
+    s = np.cross(f, up)
+    s /= np.linalg.norm(s)
+    u = np.cross(s, f)
+    M = np.eye(4)
+    M[0, :3], M[1, :3], M[2, :3] = s, u, -f
+    T = np.eye(4)
+    T[:3, 3] = -eye
+    return M @ T
+
+
+def translate(v):
+    T = np.eye(4)
+    T[:3, 3] = v
+    return T
+
+
+EYE, AT, UP = (0, 0, -7), (0, 0, 0), (0, 1, 0)          # gluvv.cpp:263-271
+LIGHT, INTENS = (0, 0, -5), 0.75                        # gluvv.cpp:293-305
+FRUSTUM = (-0.5 / 7, 0.5 / 7, -0.5 / 7, 0.5 / 7)        # unit volume fills the view
+
+
+def modelview(xform, fsize):
+    """LookAt * T(trans=0) * R(xform) * T(-fSize/2)  (VolumeRenderable.cpp:40-49)"""
+    M = look_at(EYE, AT, UP) @ xform @ translate([-f / 2 for f in fsize])
+    return [float(v) for v in M.T.reshape(-1)]  # column-major
+
+
+# --------------------------------------------------------------------------- workload set-up
+
+def make_volume(r, n, seed=1):
+    """synthetic scalar -> f32 VGH + u8 normals, all on the GPU (smk_prep.hip); returns tensors"""
+    dims = (n, n, n)
+    scalar = torch.empty((n, n, n), dtype=torch.uint8, device="cuda")
+    r.synth_volume_device(0, seed, dims, scalar.data_ptr())
+    vgh8 = torch.empty((n, n, n, 3), dtype=torch.uint8, device="cuda")
+    vghf = torch.empty((n, n, n, 3), dtype=torch.float32, device="cuda")
+    r.make_vgh_device(scalar.data_ptr(), 0, dims, 1, vgh8.data_ptr(), vghf.data_ptr())
+    nrm = torch.empty((n, n, n, 3), dtype=torch.uint8, device="cuda")
+    r.normals_vgh_device(vgh8.data_ptr(), 3, dims, 0, nrm.data_ptr())
+    del scalar, vgh8
+    return vghf, nrm
+
+
+def configure(r, workload, n, size, planes):
+    g = os.path.join(ROOT, "tests", "golden")
+    xform = rotation((1, 1, 0), 30)                     # SURVEY 8d second pose
+    xf = [float(v) for v in xform.T.reshape(-1)]
+    if workload == "cfg3":
+        r.set_tf2d(np.load(os.path.join(g, "tf_cfg3_levwidget.npy")), None)
+    else:  # cfg4: separable (v,g) x (h) classification = the reference's live 3-D TF
+        r.set_tf2d(np.load(os.path.join(g, "tf_cfg3_levwidget.npy")),
+                   np.load(os.path.join(g, "tf_h_slider05.npy")))
+    mv = modelview(xform, (1.0, 1.0, 1.0))
+    r.set_camera(mv, FRUSTUM, (1.0, 20.0), size, size)
+    r.set_sampling(0.0, planes, 1.0, 1)
+    r.set_shading("r8k", LIGHT, EYE, AT, xf, INTENS)
+    r.set_perturb(None, None, None)
+    return xform, mv
+
+
+def run_frames(r, nframes, frame, world, compositor_state):
+    """nframes frames back to back; returns nothing (caller brackets with barrier+sync)"""
+    for _ in range(nframes):
+        if world == 1:
+            r.render_device(frame.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        else:
+            pkg, partial, order, tile_out = compositor_state
+            stream = torch.cuda.current_stream().cuda_stream
+            r.render_device(partial.data_ptr(), None, stream)
+
+            def comp(layers, order_):
+                r.composite_over_device(layers.data_ptr(), world, order_, layers.shape[1],
+                                        tile_out.data_ptr(), stream)
+                return tile_out
+            tile = pkg.sortlast.exchange_and_composite(partial, order, comp)
+            full = pkg.sortlast.gather_frame(tile, 0)
+            if full is not None:
+                frame.copy_(full[:frame.shape[0]])
+
+
+def timed(r, K, W, frame, world, cstate):
+    run_frames(r, W, frame, world, cstate)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    r.timing_reset()
+    t0 = time.perf_counter()
+    run_frames(r, K, frame, world, cstate)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([t], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = float(tt.item())
+    kms, kn = r.timing_read()
+    return t, kms, kn
+
+
+def cpu_baseline(vghf, nrm, tf_path, size, planes, xform, mv, gpu_frame, budget_s=12.0):
+    """the CPU checker on the host cores, same frame, a bounded band of rows around the centre"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    sc = O.Scene(vghf.cpu().numpy(), grad=nrm.cpu().numpy())
+    sc.tf_mode, sc.tf_vg = 1, np.load(tf_path)
+    sc.width = sc.height = size
+    sc.steps = planes
+    sc.xform = [float(v) for v in xform.T.reshape(-1)]
+    sc.mv_override = mv              # the very matrix the GPU frame was rendered with
+    sc.shade_mode, sc.use_spec = 1, 1
+    sc.frustum = FRUSTUM
+    mid = size // 2
+    t0 = time.perf_counter()
+    sc.render(rows=(mid, mid + 4))
+    per_row = (time.perf_counter() - t0) / 4
+    rows = int(max(8, min(size, budget_s / max(per_row, 1e-6))))
+    rows -= rows % 2
+    a, b = mid - rows // 2, mid + rows // 2
+    t0 = time.perf_counter()
+    img = sc.render(rows=(a, b))
+    dt = time.perf_counter() - t0
+    err = float(np.abs(img[a:b] - gpu_frame[a:b]).max())
+    import ctypes
+    try:
+        threads = ctypes.CDLL("libgomp.so.1").omp_get_max_threads()
+    except OSError:
+        threads = os.cpu_count()
+    return {"value": rows * size * planes / dt / 1e6, "unit": "Msamples/s", "cores": int(threads),
+            "kind": "port",
+            "sample": "rows %d..%d of the same %dx%dx%d frame (%.1f s of CPU work)" % (a, b, size, size, planes, dt),
+            "host_cpus": os.cpu_count(), "parity_max_abs_err_vs_gpu": err}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--volume", type=int, default=512)
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--planes", type=int, default=512)
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 gather, 2 slab-staged")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-north-star", action="store_true")
+    ap.add_argument("--north-star-volume", type=int, default=1024)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if world != a.gpus and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
+
+    pkg = load_package()
+    from simian_spacemonkey_amd import sortlast  # noqa: F401
+    pkg.sortlast = sortlast
+    dev = local if world > 1 else 0
+    torch.cuda.set_device(dev)
+    r = pkg.Renderer(dev)            # raises when the HIP library / device is missing
+    r.set_option("kernel", a.kernel)
+
+    n, size, planes = a.volume, a.size, a.planes
+    vghf, nrm = make_volume(r, n)
+    if world > 1:
+        r.set_shard(rank, world)
+    r.upload_volume_device(vghf.data_ptr(), (n, n, n), 3, 1, nrm.data_ptr())
+    xform, mv = configure(r, "cfg3", n, size, planes)
+
+    npix = size * size
+    frame = torch.zeros((npix, 4), dtype=torch.float32, device="cuda")
+    cstate = None
+    if world > 1:
+        tp = sortlast.tile_pixels(npix, world)
+        partial = torch.zeros((tp * world, 4), dtype=torch.float32, device="cuda")
+        tile_out = torch.zeros((tp, 4), dtype=torch.float32, device="cuda")
+        order = r.shard_order(world)
+        cstate = (pkg, partial, order, tile_out)
+        if world > 1 and rank != 0:
+            del vghf, nrm
+            vghf = nrm = None
+
+    # everything (render kernel, RCCL exchange, composite) is enqueued on ONE non-default torch
+    # stream so its handle can be passed through the C ABI and the HIP events bracket the kernel
+    # on the stream it really runs on
+    work = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(work):
+        t, kms, kn = timed(r, a.steps, a.warmup, frame, world, cstate)
+    kernel, _, alg_bytes = r.last_frame_info()
+    ms = t / a.steps * 1e3
+    samples = float(size) * size * planes
+    out = {
+        "metric": "Msamples/s + fps, 512^3 VGH vol @1024^2 x 512 steps",
+        "value": samples / (t / a.steps) / 1e6, "unit": "Msamples/s", "fps": a.steps / t,
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "cfg3: %d^3 f32 VGH + u8 normals, 2-D LevWidget TF, R8k Phong (diff+spec), "
+                               "%dx%d viewport x %d planes, pose 30deg about (1,1,0)" % (n, size, size, planes),
+                   "volume": n, "viewport": size, "planes": planes,
+                   "parallelism": "sort-last x%d (brick shards, RCCL all-to-all + ordered over)" % world
+                   if world > 1 else "single GPU",
+                   "kernel": {1: "gather", 2: "slab-staged"}.get(kernel, str(kernel))},
+    }
+    if rank == 0:
+        ach = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                           "kernel_ms": kms, "kernel_frames_timed": kn,
+                           "algorithmic_bytes_per_launch": alg_bytes,
+                           "note": "this rank's shard; %d^3 f32 working set is VALU/LDS-bound by "
+                                   "construction (BASELINE.md sec. 2), see north_star" % n}
+    if rank == 0 and world == 1 and not a.no_cpu:
+        torch.cuda.synchronize()
+        gpu_frame = frame.view(size, size, 4).cpu().numpy()
+        out["cpu_baseline"] = cpu_baseline(vghf, nrm, os.path.join(ROOT, "tests", "golden", "tf_cfg3_levwidget.npy"),
+                                           size, planes, xform, mv, gpu_frame)
+    if rank == 0 and world == 1 and not a.no_north_star:
+        del vghf, nrm
+        torch.cuda.empty_cache()
+        nn_ = a.north_star_volume
+        v2, g2 = make_volume(r, nn_)
+        r.upload_volume_device(v2.data_ptr(), (nn_, nn_, nn_), 3, 1, g2.data_ptr())
+        del v2, g2
+        torch.cuda.empty_cache()
+        configure(r, "cfg4", nn_, size, planes)
+        k2 = max(3, min(a.steps, 10))
+        with torch.cuda.stream(work):
+            t2, kms2, kn2 = timed(r, k2, 2, frame, 1, None)
+        kernel2, _, alg2 = r.last_frame_info()
+        ach2 = alg2 / (kms2 * 1e-3) / 1e9 if kms2 > 0 else 0.0
+        out["north_star"] = {
+            "workload": "cfg4 single GPU: %d^3 f32 VGH + u8 normals, (v,g)x(h) TF, R8k Phong, %dx%dx%d" % (nn_, size, size, planes),
+            "ms_per_frame": t2 / k2 * 1e3, "fps": k2 / t2, "Msamples_per_s": samples / (t2 / k2) / 1e6,
+            "roofline": {"bound": "hbm", "achieved": ach2, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": ach2 / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": kms2,
+                         "algorithmic_bytes_per_launch": alg2},
+            "kernel": {1: "gather", 2: "slab-staged"}.get(kernel2, str(kernel2))}
+    if rank == 0:
+        print(json.dumps(out))
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -149,6 +149,10 @@ int smk_get_raycoef(smk_ctx *ctx, smk_raycoef *out);
 int smk_set_option(smk_ctx *ctx, const char *key, int value);
 /* last frame: which kernel ran (1/2), its HIP-event time in ms, algorithmic bytes */
 int smk_last_frame_info(smk_ctx *ctx, int *kernel, float *ms, double *alg_bytes);
+/* HIP-event timing of the render kernel on its launch stream: reset, render N frames, read the
+ * average (ms) over the last min(N,64) frames.  smk_timing_read synchronises the device. */
+int smk_timing_reset(smk_ctx *ctx);
+int smk_timing_read(smk_ctx *ctx, float *avg_ms, int *nframes);
 /* effective 2-D TF after opacity correction, as uploaded (sg*sv*4 bytes) */
 int smk_get_tf2d_effective(smk_ctx *ctx, unsigned char *out, float *rate_out);
 

@@ -21,6 +21,7 @@ ABI_SYMBOLS = [
     "smk_set_perturb", "smk_render", "smk_render_device", "smk_composite_over_device",
     "smk_make_vgh_device", "smk_normals_vgh_device", "smk_synth_volume_device",
     "smk_get_raycoef", "smk_set_option", "smk_last_frame_info", "smk_get_tf2d_effective",
+    "smk_timing_reset", "smk_timing_read",
 ]
 
 # gluvvDataMode order (gluvv.h:221-235)
@@ -108,6 +109,8 @@ def load_library():
     L.smk_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.smk_last_frame_info.argtypes = [C.c_void_p, P(C.c_int), P(C.c_float), P(C.c_double)]
     L.smk_get_tf2d_effective.argtypes = [C.c_void_p, C.c_void_p, P(C.c_float)]
+    L.smk_timing_reset.argtypes = [C.c_void_p]
+    L.smk_timing_read.argtypes = [C.c_void_p, P(C.c_float), P(C.c_int)]
     _LIB = L
     return L
 
@@ -276,6 +279,14 @@ class Renderer:
         k, ms, b = C.c_int(0), C.c_float(0), C.c_double(0)
         self._ck(self.L.smk_last_frame_info(self.ctx, C.byref(k), C.byref(ms), C.byref(b)))
         return k.value, ms.value, b.value
+
+    def timing_reset(self):
+        self._ck(self.L.smk_timing_reset(self.ctx))
+
+    def timing_read(self):
+        ms, n = C.c_float(0), C.c_int(0)
+        self._ck(self.L.smk_timing_read(self.ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def tf2d_effective(self, sv, sg):
         out = np.zeros((sg, sv, 4), np.uint8)

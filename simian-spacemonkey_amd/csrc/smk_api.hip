@@ -52,7 +52,7 @@ extern "C" smk_ctx *smk_create(int device_ordinal, int *err) {
   smk_ctx *c = new smk_ctx();
   c->device = device_ordinal;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+      false) {
     g_create_err = "smk_create: stream/event creation failed";
     delete c;
     if (err) *err = 4;
@@ -78,8 +78,8 @@ extern "C" void smk_destroy(smk_ctx *c) {
   void *ptrs[] = {c->d_tlut, c->d_tf_vg, c->d_tf_h, c->d_tf3d, c->d_noise, c->d_out, c->d_depth};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
-  if (c->ev0) (void)hipEventDestroy(c->ev0);
-  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  for (hipEvent_t e : c->tev0) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->tev1) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -606,6 +606,30 @@ extern "C" int smk_set_option(smk_ctx *c, const char *key, int value) {
   return 0;
 }
 
+extern "C" int smk_timing_reset(smk_ctx *c) {
+  if (!c) return 1;
+  c->tcount = 0;
+  return 0;
+}
+
+// average render-kernel duration over the frames recorded since smk_timing_reset (at most the
+// last SMK_TIMING_RING); synchronises the device
+extern "C" int smk_timing_read(smk_ctx *c, float *avg_ms, int *nframes) {
+  if (!c) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  int n = (int)std::min<long long>(c->tcount, SMK_TIMING_RING);
+  double sum = 0;
+  for (int i = 0; i < n; ++i) {
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->tev0[i], c->tev1[i]));
+    sum += ms;
+  }
+  if (avg_ms) *avg_ms = n ? (float)(sum / n) : 0.f;
+  if (nframes) *nframes = n;
+  return 0;
+}
+
 extern "C" int smk_last_frame_info(smk_ctx *c, int *kernel, float *ms, double *alg_bytes) {
   if (!c) return 1;
   if (kernel) *kernel = c->last_kernel;
@@ -698,10 +722,22 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
                : c->tf_mode == 1 ? 4.0 * c->sv * c->sg * (P.third_axis ? 2 : 1)
                                  : 4.0 * c->s3v * c->s3g * c->s3h;
   c->last_alg_bytes = (double)nst * bv + tfb + 16.0 * c->W * c->H;
+  if (c->tev0.empty()) {
+    c->tev0.resize(SMK_TIMING_RING);
+    c->tev1.resize(SMK_TIMING_RING);
+    for (int i = 0; i < SMK_TIMING_RING; ++i) {
+      HIPCHK(c, hipEventCreate(&c->tev0[i]));
+      HIPCHK(c, hipEventCreate(&c->tev1[i]));
+    }
+  }
+  int slot = (int)(c->tcount % SMK_TIMING_RING);
+  c->ev0 = c->tev0[slot];
+  c->ev1 = c->tev1[slot];
   HIPCHK(c, hipEventRecord(c->ev0, s));
   c->last_kernel = 1;
   HIPCHK(c, smk_launch_gather(P, c->dtype, c->tf_mode, shade_kind_of(c), s));
   HIPCHK(c, hipEventRecord(c->ev1, s));
+  c->tcount++;
   return 0;
 }
 

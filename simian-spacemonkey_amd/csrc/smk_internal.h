@@ -10,6 +10,7 @@
 #include "../../include/smk.h"
 
 #define SMK_MAX_RANKS 8
+#define SMK_TIMING_RING 64
 
 // Everything a render kernel needs, passed by value as the kernarg (wave-uniform => SGPRs).
 struct RenderParams {
@@ -59,6 +60,10 @@ struct smk_ctx {
   std::string err;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // ring of HIP-event pairs bracketing the render kernel of the last SMK_TIMING_RING frames,
+  // recorded on the stream the kernel is launched on (bench.py's roofline leg reads them)
+  std::vector<hipEvent_t> tev0, tev1;
+  long long tcount = 0;
 
   // volume
   bool have_volume = false;

@@ -1,15 +1,396 @@
-// smk_prep.hip -- data preparation on the GPU, filled in below.
+// smk_prep.hip -- data preparation on the GPU: the step before the hot path.
+//
+//   smk_make_vgh_device      genVGH makeVGH<T>                 genVGH/main.cpp:56-182
+//   smk_normals_vgh_device   MetaVolume::normalsVGH            MetaVolume.cpp:1274-1324
+//                            = derivative3DVGH + blurV3D + scalebiasN
+//                                                              VectorMath.h:874-899, 1217-1281, 1133-1148
+//   smk_synth_volume_device  bench/test input generator (no reference equivalent; genvol's
+//                            Perlin tables depend on libc rand(), so the GPU generator is analytic)
+//
+// These are HBM-streaming stencils over bytes/floats; results are integers (u8), so the float
+// expressions follow the reference's evaluation order exactly (compile with -ffp-contract=off)
+// and the outputs are bit-identical to the CPU restatement.  Nothing is staged in temporaries
+// for VGH: gradients are recomputed from the L2-resident neighbourhood (two passes: min/max
+// statistics, then quantise), which keeps the 1024^3 case at zero extra HBM footprint.
+#include <string.h>
+
+#include <algorithm>
+
 #include "smk_internal.h"
 
-extern "C" int smk_make_vgh_device(smk_ctx *c, const void *, smk_dtype, int, int, int, int, void *, void *) {
-  if (c) c->err = "smk_make_vgh_device: not implemented yet";
-  return 1;
+#define PCHK(ctx, call)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      (ctx)->err = std::string(#call) + " failed: " + hipGetErrorString(e_);             \
+      return 1;                                                                           \
+    }                                                                                     \
+  } while (0)
+
+// ------------------------------------------------------------------------------- helpers
+
+// order-preserving float <-> int map so min/max can use integer atomics
+__device__ __forceinline__ int f2o(float f) {
+  int i = __float_as_int(f);
+  return i >= 0 ? i : i ^ 0x7fffffff;
 }
-extern "C" int smk_normals_vgh_device(smk_ctx *c, const void *, int, int, int, int, int, void *) {
-  if (c) c->err = "smk_normals_vgh_device: not implemented yet";
-  return 1;
+__host__ __device__ __forceinline__ float o2f(int i) {
+  int j = i >= 0 ? i : i ^ 0x7fffffff;
+#ifdef __HIP_DEVICE_COMPILE__
+  return __int_as_float(j);
+#else
+  float f;
+  memcpy(&f, &j, 4);
+  return f;
+#endif
 }
-extern "C" int smk_synth_volume_device(smk_ctx *c, int, unsigned, int, int, int, void *) {
-  if (c) c->err = "smk_synth_volume_device: not implemented yet";
-  return 1;
+
+struct VghStats {  // ordered-int encoded
+  int dmin, dmax, gmin, gmax, hmin, hmax;
+};
+
+template <int DT>
+__device__ __forceinline__ float ld(const void *d, size_t i) {
+  return DT == 0 ? (float)((const unsigned char *)d)[i] : ((const float *)d)[i];
+}
+
+// un-normalised central differences (genVGH/main.cpp:86-88); u8 differences are exact ints
+template <int DT>
+__device__ __forceinline__ void grad_at(const void *d, int sx, int sy, int i, int j, int k, float g[3]) {
+  size_t sxy = (size_t)sx * sy, o = (size_t)i * sxy + (size_t)j * sx + k;
+  g[0] = ld<DT>(d, o + 1) - ld<DT>(d, o - 1);
+  g[1] = ld<DT>(d, o + sx) - ld<DT>(d, o - sx);
+  g[2] = ld<DT>(d, o + sxy) - ld<DT>(d, o - sxy);
+}
+
+__device__ __forceinline__ bool is_border(int sx, int sy, int sz, int i, int j, int k) {
+  return (k < 1) || (k > sx - 2) || (j < 1) || (j > sy - 2) || (i < 1) || (i > sz - 2);
+}
+
+// gradient of a neighbour: zero on the 1-voxel border (:79-84)
+template <int DT>
+__device__ __forceinline__ void grad_nb(const void *d, int sx, int sy, int sz, int i, int j, int k, float g[3]) {
+  if (is_border(sx, sy, sz, i, j, k)) {
+    g[0] = g[1] = g[2] = 0.f;
+  } else {
+    grad_at<DT>(d, sx, sy, i, j, k, g);
+  }
+}
+
+// gradient magnitude + second derivative along the gradient for an interior voxel (:110-146)
+template <int DT>
+__device__ __forceinline__ void gh_at(const void *d, int sx, int sy, int sz, int i, int j, int k, int compat,
+                                      float &gm, float &hs) {
+  float g[3];
+  grad_at<DT>(d, sx, sy, i, j, k, g);
+  gm = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+  float xp[3], xm[3], yp[3], ym[3], zp[3], zm[3];
+  grad_nb<DT>(d, sx, sy, sz, i, j, k + 1, xp);
+  grad_nb<DT>(d, sx, sy, sz, i, j, k - 1, xm);
+  grad_nb<DT>(d, sx, sy, sz, i, j + 1, k, yp);
+  grad_nb<DT>(d, sx, sy, sz, i, j - 1, k, ym);
+  grad_nb<DT>(d, sx, sy, sz, i + 1, j, k, zp);
+  grad_nb<DT>(d, sx, sy, sz, i - 1, j, k, zm);
+  float h[9];
+  h[0] = xp[0] - xm[0];
+  h[1] = yp[0] - ym[0];
+  h[2] = zp[0] - zm[0];
+  h[3] = xp[1] - xm[1];
+  h[4] = yp[1] - ym[1];
+  h[5] = zp[1] - zm[1];
+  h[6] = xp[2] - xm[2];
+  h[7] = yp[2] - ym[2];
+  h[8] = zp[2] - zm[2];
+  float tg[3] = {g[0] / gm, g[1] / gm, g[2] / gm};
+  float tv0 = tg[0] * h[0] + tg[1] * h[1] + tg[2] * h[2];
+  // the reference drops h[4] here (genVGH/main.cpp:135-137); compat keeps the typo
+  float tv1 = compat ? tg[0] * h[3] + tg[1] + tg[2] * h[5] : tg[0] * h[3] + tg[1] * h[4] + tg[2] * h[5];
+  float tv2 = tg[0] * h[6] + tg[1] * h[7] + tg[2] * h[8];
+  hs = tg[0] * tv0 + tg[1] * tv1 + tg[2] * tv2;
+}
+
+__device__ __forceinline__ int wave_min(int v) {
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+#define ORD_POS_INF 0x7f800000
+// f2o(-inf) = 0xff800000 ^ 0x7fffffff = 0x807fffff
+
+template <int DT>
+__global__ __launch_bounds__(256) void smk_k_vgh_stats(const void *d, int sx, int sy, int sz, int compat,
+                                                       VghStats *st) {
+  size_t n = (size_t)sx * sy * sz;
+  int dmin = ORD_POS_INF, dmax = (int)0x807fffff, gmin = ORD_POS_INF, gmax = (int)0x807fffff;
+  int hmin = ORD_POS_INF, hmax = (int)0x807fffff;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    int k = (int)(t % sx), j = (int)((t / sx) % sy), i = (int)(t / ((size_t)sx * sy));
+    if (is_border(sx, sy, sz, i, j, k)) continue;
+    float gm, hs;
+    gh_at<DT>(d, sx, sy, sz, i, j, k, compat, gm, hs);
+    float dv = ld<DT>(d, t);
+    dmin = min(dmin, f2o(dv));
+    dmax = max(dmax, f2o(dv));
+    gmin = min(gmin, f2o(gm));
+    gmax = max(gmax, f2o(gm));
+    if (hs == hs) {  // NaN (zero gradient) never wins the reference's MAX/MIN macros
+      hmin = min(hmin, f2o(hs));
+      hmax = max(hmax, f2o(hs));
+    }
+  }
+  dmin = wave_min(dmin);
+  dmax = wave_max(dmax);
+  gmin = wave_min(gmin);
+  gmax = wave_max(gmax);
+  hmin = wave_min(hmin);
+  hmax = wave_max(hmax);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&st->dmin, dmin);
+    atomicMax(&st->dmax, dmax);
+    atomicMin(&st->gmin, gmin);
+    atomicMax(&st->gmax, gmax);
+    atomicMin(&st->hmin, hmin);
+    atomicMax(&st->hmax, hmax);
+  }
+}
+
+__device__ __forceinline__ double affine_d(double i, double x, double I, double o, double O) {
+  return ((O) - (o)) * ((x) - (i)) / ((I) - (i)) + (o);
+}
+
+// (unsigned char) cast as x86 does it: truncate through int32, low byte; NaN/out of range -> 0
+__device__ __forceinline__ unsigned char uc_cast(double x) {
+  if (!(x > -2147483649.0 && x < 2147483648.0)) return 0;
+  return (unsigned char)((int)x & 0xff);
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void smk_k_vgh_quant(const void *d, int sx, int sy, int sz, int compat,
+                                                       float dmin, float dmax, float gmmin, float gmmax, float hmin,
+                                                       float hmax, unsigned char *o8, float *of) {
+  size_t n = (size_t)sx * sy * sz;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    int k = (int)(t % sx), j = (int)((t / sx) % sy), i = (int)(t / ((size_t)sx * sy));
+    unsigned char q0 = 0, q1 = 0, q2 = 0;
+    float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+    if (!is_border(sx, sy, sz, i, j, k)) {
+      float gm, hs;
+      gh_at<DT>(d, sx, sy, sz, i, j, k, compat, gm, hs);
+      // genVGH/main.cpp:164-175
+      double vq = affine_d(dmin, ld<DT>(d, t), dmax, 0, 255);
+      double gq = affine_d(gmmin, gm, gmmax, 0, 255);
+      double hq;
+      if (hs < 0) {
+        float th = (float)affine_d(hmin, hs, 0, 0, 1);
+        hq = affine_d(0, th, 1, 0, 255 / 3);
+      } else {
+        float th = (float)affine_d(0, hs, hmax, 0, 1);
+        hq = affine_d(0, th, 1, 255 / 3, 255 / 3 * 2);
+      }
+      q0 = uc_cast(vq);
+      q1 = uc_cast(gq);
+      q2 = uc_cast(hq);
+      f0 = (float)(vq / 255.0);
+      f1 = (float)(gq / 255.0);
+      f2 = (hq == hq) ? (float)(hq / 255.0) : 0.0f;
+    }
+    if (o8) {
+      o8[t * 3 + 0] = q0;
+      o8[t * 3 + 1] = q1;
+      o8[t * 3 + 2] = q2;
+    }
+    if (of) {
+      of[t * 3 + 0] = f0;
+      of[t * 3 + 1] = f1;
+      of[t * 3 + 2] = f2;
+    }
+  }
+}
+
+extern "C" int smk_make_vgh_device(smk_ctx *c, const void *d, smk_dtype dt, int sx, int sy, int sz, int compat,
+                                   void *o8, void *of) {
+  if (!c) return 1;
+  PCHK(c, hipSetDevice(c->device));
+  if (!d || (!o8 && !of) || sx < 3 || sy < 3 || sz < 3) {
+    c->err = "smk_make_vgh_device: bad arguments (need dims >= 3 and one output)";
+    return 1;
+  }
+  VghStats *st = nullptr;
+  PCHK(c, hipMalloc((void **)&st, sizeof(VghStats)));
+  VghStats init = {ORD_POS_INF, (int)0x807fffff, ORD_POS_INF, (int)0x807fffff, ORD_POS_INF, (int)0x807fffff};
+  PCHK(c, hipMemcpy(st, &init, sizeof init, hipMemcpyHostToDevice));
+  size_t n = (size_t)sx * sy * sz;
+  unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 16);
+  if (dt == SMK_U8) hipLaunchKernelGGL(smk_k_vgh_stats<0>, dim3(blocks), dim3(256), 0, c->stream, d, sx, sy, sz, compat, st);
+  else hipLaunchKernelGGL(smk_k_vgh_stats<1>, dim3(blocks), dim3(256), 0, c->stream, d, sx, sy, sz, compat, st);
+  PCHK(c, hipGetLastError());
+  PCHK(c, hipStreamSynchronize(c->stream));
+  VghStats h;
+  PCHK(c, hipMemcpy(&h, st, sizeof h, hipMemcpyDeviceToHost));
+  (void)hipFree(st);
+  // the reference seeds its running min/max with +-1e8 (genVGH/main.cpp:69-72, 104-105)
+  float dmin = std::min(o2f(h.dmin), 100000000.f), dmax = std::max(o2f(h.dmax), -100000000.f);
+  float gmin = std::min(o2f(h.gmin), 100000000.f), gmax = std::max(o2f(h.gmax), -100000000.f);
+  float hmin = std::min(o2f(h.hmin), 100000000.f), hmax = std::max(o2f(h.hmax), -100000000.f);
+  if (dt == SMK_U8)
+    hipLaunchKernelGGL(smk_k_vgh_quant<0>, dim3(blocks), dim3(256), 0, c->stream, d, sx, sy, sz, compat, dmin, dmax,
+                       gmin, gmax, hmin, hmax, (unsigned char *)o8, (float *)of);
+  else
+    hipLaunchKernelGGL(smk_k_vgh_quant<1>, dim3(blocks), dim3(256), 0, c->stream, d, sx, sy, sz, compat, dmin, dmax,
+                       gmin, gmax, hmin, hmax, (unsigned char *)o8, (float *)of);
+  PCHK(c, hipGetLastError());
+  PCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------- normals
+
+// derivative3DVGH: int central differences of channel 0, 0 on the border (VectorMath.h:874-899)
+__device__ __forceinline__ void nrm_grad(const unsigned char *d, int ne, int sx, int sy, int sz, int i, int j, int k,
+                                         float g[3]) {
+  if (is_border(sx, sy, sz, i, j, k)) {
+    g[0] = g[1] = g[2] = 0.f;
+    return;
+  }
+  size_t sxy = (size_t)sx * sy, o = (size_t)i * sxy + (size_t)j * sx + k;
+  g[0] = (float)((int)d[(o + 1) * ne] - (int)d[(o - 1) * ne]);
+  g[1] = (float)((int)d[(o + sx) * ne] - (int)d[(o - sx) * ne]);
+  g[2] = (float)((int)d[(o + sxy) * ne] - (int)d[(o - sxy) * ne]);
+}
+
+// scalebiasN (VectorMath.h:1133-1148) with the +1 -> 255 clamp
+__device__ __forceinline__ void nrm_store(float g[3], unsigned char *out) {
+  float len = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+  if (len > 0) {
+    g[0] /= len;
+    g[1] /= len;
+    g[2] /= len;
+  }
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    float s = g[e] * 128 + 128;
+    out[e] = s >= 255.0f ? 255 : (unsigned char)((int)s & 0xff);
+  }
+}
+
+__global__ __launch_bounds__(256) void smk_k_normals(const unsigned char *d, int ne, int sx, int sy, int sz, int blur,
+                                                     unsigned char *out) {
+  size_t n = (size_t)sx * sy * sz;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    int k = (int)(t % sx), j = (int)((t / sx) % sy), i = (int)(t / ((size_t)sx * sy));
+    float g[3];
+    if (!blur) {
+      nrm_grad(d, ne, sx, sy, sz, i, j, k, g);
+    } else {
+      // blurV3D is a scatter from every interior voxel to its 27 neighbours in raster order
+      // of the SOURCE (VectorMath.h:1232-1266).  Gathering the same terms in the same order
+      // (source raster order == ascending di,dj,dk) reproduces the float sums bit for bit.
+      const float w[4] = {1.0f, .3f, .2f, .1f};  // MetaVolume.cpp:1316
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      for (int di = -1; di <= 1; ++di)
+        for (int dj = -1; dj <= 1; ++dj)
+          for (int dk = -1; dk <= 1; ++dk) {
+            int si = i + di, sj = j + dj, sk = k + dk;
+            // only interior voxels scatter (loops run 1..n-2)
+            if (si < 1 || si > sz - 2 || sj < 1 || sj > sy - 2 || sk < 1 || sk > sx - 2) continue;
+            float s[3];
+            nrm_grad(d, ne, sx, sy, sz, si, sj, sk, s);
+            float ww = w[(di != 0) + (dj != 0) + (dk != 0)];
+            a0 = a0 + ww * s[0];
+            a1 = a1 + ww * s[1];
+            a2 = a2 + ww * s[2];
+          }
+      const float div = 1.0f + 6 * .3f + 12 * .2f + 8 * .1f;
+      g[0] = a0 / div;
+      g[1] = a1 / div;
+      g[2] = a2 / div;
+    }
+    nrm_store(g, out + t * 3);
+  }
+}
+
+extern "C" int smk_normals_vgh_device(smk_ctx *c, const void *d, int ne, int sx, int sy, int sz, int blur,
+                                      void *out) {
+  if (!c) return 1;
+  PCHK(c, hipSetDevice(c->device));
+  if (!d || !out || ne < 1 || sx < 1 || sy < 1 || sz < 1) {
+    c->err = "smk_normals_vgh_device: bad arguments";
+    return 1;
+  }
+  size_t n = (size_t)sx * sy * sz;
+  unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(smk_k_normals, dim3(blocks), dim3(256), 0, c->stream, (const unsigned char *)d, ne, sx, sy, sz,
+                     blur, (unsigned char *)out);
+  PCHK(c, hipGetLastError());
+  PCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------- synthetic volume
+
+__device__ __forceinline__ uint32_t hash3(uint32_t x, uint32_t y, uint32_t z, uint32_t s) {
+  uint32_t h = x * 0x8da6b343u ^ y * 0xd8163841u ^ z * 0xcb1ab31fu ^ s * 0x9e3779b9u;
+  h ^= h >> 16;
+  h *= 0x7feb352du;
+  h ^= h >> 15;
+  h *= 0x846ca68bu;
+  h ^= h >> 16;
+  return h;
+}
+
+// lattice value noise in [-1,1], smoothstep-interpolated
+__device__ __forceinline__ float vnoise(float x, float y, float z, uint32_t seed) {
+  float fx = floorf(x), fy = floorf(y), fz = floorf(z);
+  int ix = (int)fx, iy = (int)fy, iz = (int)fz;
+  float tx = x - fx, ty = y - fy, tz = z - fz;
+  tx = tx * tx * (3.f - 2.f * tx);
+  ty = ty * ty * (3.f - 2.f * ty);
+  tz = tz * tz * (3.f - 2.f * tz);
+  float v[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    v[q] = (float)(hash3(ix + (q & 1), iy + ((q >> 1) & 1), iz + (q >> 2), seed) >> 8) * (2.0f / 16777216.0f) - 1.0f;
+  float a = v[0] + tx * (v[1] - v[0]), b = v[2] + tx * (v[3] - v[2]);
+  float cc = v[4] + tx * (v[5] - v[4]), dd = v[6] + tx * (v[7] - v[6]);
+  float e = a + ty * (b - a), f = cc + ty * (dd - cc);
+  return e + tz * (f - e);
+}
+
+// kind 0: smooth concentric shells whose radius is perturbed by 3 octaves of value noise --
+// the shape of genvol's "-spheres 4 -p .. -pabs" volumes (genvol/main.cpp:212-256) without
+// the staircase, so gradients and second derivatives are non-degenerate everywhere
+__global__ __launch_bounds__(256) void smk_k_synth(int kind, uint32_t seed, int sx, int sy, int sz,
+                                                   unsigned char *out) {
+  size_t n = (size_t)sx * sy * sz;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    int k = (int)(t % sx), j = (int)((t / sx) % sy), i = (int)(t / ((size_t)sx * sy));
+    float x = (k + 0.5f) / sx, y = (j + 0.5f) / sy, z = (i + 0.5f) / sz;
+    float dx = x - .5f, dy = y - .5f, dz = z - .5f;
+    float r = sqrtf(dx * dx + dy * dy + dz * dz);
+    float nz = vnoise(x * 4.f, y * 4.f, z * 4.f, seed) + 0.5f * vnoise(x * 8.f, y * 8.f, z * 8.f, seed + 1) +
+               0.25f * vnoise(x * 16.f, y * 16.f, z * 16.f, seed + 2);
+    float rr = fminf(fmaxf(r + 0.06f * nz, 0.f), .5f);
+    float s = 1.f - 2.f * rr;
+    float v = s * (0.62f + 0.38f * __cosf(15.f * s));
+    out[t] = (unsigned char)(fminf(fmaxf(v, 0.f), 1.f) * 255.f + 0.5f);
+  }
+}
+
+extern "C" int smk_synth_volume_device(smk_ctx *c, int kind, unsigned seed, int sx, int sy, int sz, void *out) {
+  if (!c) return 1;
+  PCHK(c, hipSetDevice(c->device));
+  if (!out || kind != 0 || sx < 1 || sy < 1 || sz < 1) {
+    c->err = "smk_synth_volume_device: bad arguments (kind must be 0)";
+    return 1;
+  }
+  size_t n = (size_t)sx * sy * sz;
+  unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(smk_k_synth, dim3(blocks), dim3(256), 0, c->stream, kind, seed, sx, sy, sz, (unsigned char *)out);
+  PCHK(c, hipGetLastError());
+  PCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
 }
