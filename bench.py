@@ -171,7 +171,7 @@ def cpu_baseline(vghf, nrm, tf_path, size, planes, xform, mv, gpu_frame, budget_
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     sc = O.Scene(vghf.cpu().numpy(), grad=nrm.cpu().numpy())
-    sc.tf_mode, sc.tf_vg = 1, np.load(tf_path)
+    sc.tf_mode, sc.tf_vg = 1, tf_path   # the opacity-corrected table the GPU frame used
     sc.width = sc.height = size
     sc.steps = planes
     sc.xform = [float(v) for v in xform.T.reshape(-1)]
@@ -286,8 +286,8 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu:
         torch.cuda.synchronize()
         gpu_frame = frame.view(size, size, 4).cpu().numpy()
-        out["cpu_baseline"] = cpu_baseline(vghf, nrm, os.path.join(ROOT, "tests", "golden", "tf_cfg3_levwidget.npy"),
-                                           size, planes, xform, mv, gpu_frame)
+        tf_eff, _ = r.tf2d_effective(256, 256)
+        out["cpu_baseline"] = cpu_baseline(vghf, nrm, tf_eff, size, planes, xform, mv, gpu_frame)
     if rank == 0 and world == 1 and not a.no_north_star:
         del vghf, nrm
         torch.cuda.empty_cache()
