@@ -1,0 +1,70 @@
+"""Sort-last on the GPU: P shard contexts on one device render their regions, the HIP
+compositor merges them in the order smk_shard_order returns; result == unsharded frame and
+== the CPU checker.  (RCCL itself is exercised by bench.py --gpus N; the exchange plumbing by
+tests/test_sortlast_cpu.py.)"""
+import numpy as np
+import pytest
+
+from _scenes import make_scene, push_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("pose", ["rot", "back"])
+def test_sharded_frames_composite_to_whole(gpu_renderer_factory, smk, world, pose):
+    import torch
+    from simian_spacemonkey_amd import sortlast
+    sc = make_scene("cfg3", n=32, size=48, steps=48, pose=pose, f32=True, shade=1)
+    ref = sc.render()
+    npix = sc.width * sc.height
+    layers = torch.zeros((world, npix, 4), dtype=torch.float32, device="cuda")
+    rs = []
+    try:
+        for r in range(world):
+            R = gpu_renderer_factory()
+            rs.append(R)
+            R.set_shard(r, world)
+            push_scene(R, sc)
+            R.render_device(layers[r].data_ptr(), None, None)
+        torch.cuda.synchronize()
+        order = rs[0].shard_order(world)
+        # the C++ BSP rule agrees with the Python mirror used by the CPU tests
+        mv = np.array(sc.mv()).reshape(4, 4).T
+        eye = np.linalg.inv(mv)[:3, 3]
+        eye_vox = [eye[a] * sc.dims[a] / float(sc.fsize[a]) - 0.5 for a in range(3)]
+        assert order == sortlast.front_to_back_order(eye_vox, sc.dims, world)
+        out = torch.zeros((npix, 4), dtype=torch.float32, device="cuda")
+        rs[0].composite_over_device(layers.data_ptr(), world, order, npix, out.data_ptr(), None)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().reshape(sc.height, sc.width, 4)
+        assert np.abs(got - ref).max() <= 1e-4
+        # each shard alone equals the checker restricted to that region
+        sc.region = sortlast.shard_region(sc.dims, world - 1, world)
+        part = layers[world - 1].cpu().numpy().reshape(sc.height, sc.width, 4)
+        assert np.abs(part - sc.render()).max() <= 1e-4
+    finally:
+        for R in rs:
+            R.close()
+
+
+def test_perturbation_needs_halo_when_sharded(gpu_renderer_factory, smk):
+    sc = make_scene("cfg3", n=32, pert=True, shade=1)
+    R = gpu_renderer_factory()
+    try:
+        R.set_shard(0, 2)
+        push_scene(R, sc)
+        with pytest.raises(smk.SmkError, match="halo"):
+            R.render()
+    finally:
+        R.close()
+    R = gpu_renderer_factory()
+    try:
+        R.set_shard(1, 2)
+        R.set_option("halo", 8)
+        push_scene(R, sc)
+        from simian_spacemonkey_amd import sortlast
+        sc.region = sortlast.shard_region(sc.dims, 1, 2)
+        assert np.abs(R.render() - sc.render()).max() <= 1e-4
+    finally:
+        R.close()
