@@ -65,6 +65,8 @@ extern "C" smk_ctx *smk_create(int device_ordinal, int *err) {
 static void free_volume(smk_ctx *c) {
   if (c->d_vox) (void)hipFree(c->d_vox);
   if (c->d_nrm) (void)hipFree(c->d_nrm);
+  if (c->d_vox_x) (void)hipFree(c->d_vox_x);
+  c->d_vox_x = nullptr;
   c->d_vox = nullptr;
   c->d_nrm = nullptr;
   c->have_volume = false;
@@ -593,6 +595,14 @@ extern "C" int smk_set_option(smk_ctx *c, const char *key, int value) {
   if (!c || !key) return 1;
   if (!strcmp(key, "kernel")) c->opt_kernel = value;
   else if (!strcmp(key, "slab_T")) c->opt_slab_T = value;
+  else if (!strcmp(key, "tile")) c->opt_tile = value;
+  else if (!strcmp(key, "wave_w")) {
+    if (!(value == 1 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == 64)) FAIL(c, "smk_set_option: wave_w must be a power of two <= 64");
+    c->opt_wave_w = value;
+  } else if (!strcmp(key, "blk_w")) {
+    if (!(value == 1 || value == 2 || value == 4)) FAIL(c, "smk_set_option: blk_w must be 1, 2 or 4");
+    c->opt_blk_w = value;
+  } else if (!strcmp(key, "lockstep")) c->opt_lockstep = value;
   else if (!strcmp(key, "tf_raw")) {  // the 2-D TF handed over is already opacity-corrected
     c->opt_tf_raw = value;
     c->tf_dirty = true;
@@ -692,9 +702,47 @@ static int build_params(smk_ctx *c, RenderParams &P) {
         FAIL(c, "smk_render: perturbation needs halo >= %d voxels on a sharded volume (have %d); set option 'halo' before upload", need, c->halo);
     }
   }
-  P.ntx = (c->W + 15) / 16;
-  P.nty = (c->H + 15) / 16;
+  P.wave_w = c->opt_wave_w;
+  P.blk_w = c->opt_blk_w;
+  P.lockstep = c->opt_lockstep;
+  int tw = P.wave_w * P.blk_w, th = (64 / P.wave_w) * (4 / P.blk_w);
+  P.ntx = (c->W + tw - 1) / tw;
+  P.nty = (c->H + th - 1) / th;
   P.tiles_per_xcd = (P.ntx * P.nty + 7) / 8;
+  return 0;
+}
+
+// [z][y][x] -> [x][z][y] so that views along x also read contiguous rows (288 GB of HBM buys a
+// second layout; only one copy is read per frame).  32x32 tiles through LDS keep both sides
+// coalesced in 16-byte (f32: 2 x 8-byte) units.
+template <class V>
+__global__ __launch_bounds__(256) void smk_k_xmajor(const V *src, V *dst, int Dx, int Dy, int Dz) {
+  __shared__ V tile[32][33];
+  int z = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    int x = x0 + tx, y = y0 + r;
+    if (x < Dx && y < Dy) tile[r][tx] = src[((size_t)z * Dy + y) * Dx + x];
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    int x = x0 + r, y = y0 + tx;
+    if (x < Dx && y < Dy) dst[((size_t)x * Dz + z) * Dy + y] = tile[tx][r];
+  }
+}
+
+static int make_xmajor_copy(smk_ctx *c) {
+  if (c->d_vox_x) return 0;
+  HIPCHK(c, hipMalloc(&c->d_vox_x, c->vox_bytes));
+  dim3 grid((c->D[0] + 31) / 32, (c->D[1] + 31) / 32, c->D[2]);
+  if (c->dtype == SMK_U8)
+    hipLaunchKernelGGL(smk_k_xmajor<uint2>, grid, dim3(256), 0, c->stream, (const uint2 *)c->d_vox, (uint2 *)c->d_vox_x,
+                       c->D[0], c->D[1], c->D[2]);
+  else
+    hipLaunchKernelGGL(smk_k_xmajor<float4>, grid, dim3(256), 0, c->stream, (const float4 *)c->d_vox,
+                       (float4 *)c->d_vox_x, c->D[0], c->D[1], c->D[2]);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
 
@@ -734,8 +782,28 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
   c->ev0 = c->tev0[slot];
   c->ev1 = c->tev1[slot];
   HIPCHK(c, hipEventRecord(c->ev0, s));
+  // kernel choice: the slice-ring kernel when it applies (2-D / separable classification,
+  // no perturbation, rays sharing one principal axis), the generic gather kernel otherwise
   c->last_kernel = 1;
-  HIPCHK(c, smk_launch_gather(P, c->dtype, c->tf_mode, shade_kind_of(c), s));
+  c->slab_why.clear();
+  if (c->opt_kernel != 1 && c->tf_mode == 1) {
+    const char *why = nullptr;
+    hipError_t e = smk_launch_slab(P, c->dtype, shade_kind_of(c), c->opt_slab_T, c->opt_tile, c->d_vox,
+                                   c->d_vox_x, &why, s);
+    if (e == hipErrorNotSupported && why && !strcmp(why, "x-major copy unavailable")) {
+      if (make_xmajor_copy(c)) return 1;
+      e = smk_launch_slab(P, c->dtype, shade_kind_of(c), c->opt_slab_T, c->opt_tile, c->d_vox, c->d_vox_x, &why, s);
+    }
+    if (e == hipSuccess) c->last_kernel = 2;
+    else if (e == hipErrorNotSupported) {
+      c->slab_why = why ? why : "?";
+      if (c->opt_kernel == 2) FAIL(c, "smk_render: slab kernel forced but not applicable: %s", c->slab_why.c_str());
+    } else
+      HIPCHK(c, e);
+  } else if (c->opt_kernel == 2) {
+    FAIL(c, "smk_render: slab kernel forced but classification mode %d is gather-only", c->tf_mode);
+  }
+  if (c->last_kernel == 1) HIPCHK(c, smk_launch_gather(P, c->dtype, c->tf_mode, shade_kind_of(c), s));
   HIPCHK(c, hipEventRecord(c->ev1, s));
   c->tcount++;
   return 0;

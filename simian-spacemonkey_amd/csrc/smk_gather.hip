@@ -15,9 +15,11 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
   int tx, ty;
   if (!smk_tile_of_block(P, blockIdx.x, tx, ty)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = tx * 16 + (wave & 1) * 8 + (lane & 7);
-  const int j = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
-  if (i >= P.W || j >= P.H) return;
+  // wave sub-tile wave_w x (64/wave_w) pixels, blk_w x (4/blk_w) waves per workgroup
+  const int wh = 64 / P.wave_w, bh = 4 / P.blk_w;
+  const int i = tx * (P.wave_w * P.blk_w) + (wave % P.blk_w) * P.wave_w + (lane % P.wave_w);
+  const int j = ty * (wh * bh) + (wave / P.blk_w) * wh + (lane / P.wave_w);
+  const bool live = i < P.W && j < P.H;
 
   const smk_raycoef &rc = P.rc;
   const float px = __fmaf_rn((float)i + 0.5f, rc.pxs, rc.pxl);
@@ -46,13 +48,26 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
   }
   int m0 = (int)floorf(fmaxf(tenter, 0.0f));
   int m1 = (int)ceilf(fminf(texit, (float)(rc.nplanes - 1)));
-  if (empty || !(tenter <= texit)) m1 = m0 - 1;
+  if (empty || !(tenter <= texit) || !live) m1 = m0 - 1;
+  int mlo = m0, mhi = m1;
+  if (P.lockstep) {
+    // all 64 rays of the wave visit the same plane in the same iteration: their corner
+    // fetches then fall in one thin slab of the volume instead of 64 different depths
+    int lo = m1 >= m0 ? m0 : 0x7fffffff, hi = m1 >= m0 ? m1 : -0x7fffffff;
+    for (int o = 32; o > 0; o >>= 1) {
+      lo = min(lo, __shfl_xor(lo, o));
+      hi = max(hi, __shfl_xor(hi, o));
+    }
+    mlo = lo;
+    mhi = hi;
+  }
 
   float C0 = 0.f, C1 = 0.f, C2 = 0.f, C3 = 0.f;
   float first = __int_as_float(0x7f800000);
   const int Dx = P.D[0], Dy = P.D[1];
 
-  for (int m = m0; m <= m1; ++m) {
+  for (int m = mlo; m <= mhi; ++m) {
+    if (m < m0 || m > m1) continue;
     float p0 = __fmaf_rn((float)m, B[0], A[0]);
     float p1 = __fmaf_rn((float)m, B[1], A[1]);
     float p2 = __fmaf_rn((float)m, B[2], A[2]);
@@ -138,6 +153,7 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
     C2 = __fmaf_rn(w, src.z, C2);
     C3 = __fmaf_rn(w, src.w, C3);
   }
+  if (!live) return;
   size_t o = (size_t)j * P.W + i;
   P.out[o] = make_float4(C0, C1, C2, C3);
   if (P.depth) P.depth[o] = first;

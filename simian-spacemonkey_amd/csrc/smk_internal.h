@@ -53,6 +53,7 @@ struct RenderParams {
   float *depth;
   // ---- tile mapping
   int ntx, nty, tiles_per_xcd;
+  int wave_w, blk_w, lockstep;  // gather-kernel tiling knobs (smk_set_option)
 };
 
 struct smk_ctx {
@@ -74,6 +75,8 @@ struct smk_ctx {
   int O[3] = {0, 0, 0}, D[3] = {0, 0, 0};
   int halo = 1;
   void *d_vox = nullptr;
+  void *d_vox_x = nullptr;  // x-major copy [x][z][y] for views whose principal axis is x (lazy)
+  std::string slab_why;     // why the last frame fell back to the gather kernel ("" if it did not)
   uint32_t *d_nrm = nullptr;
   bool have_normals = false;
   size_t vox_bytes = 0;
@@ -118,7 +121,8 @@ struct smk_ctx {
   size_t out_cap = 0;
 
   // options / stats
-  int opt_kernel = 0, opt_slab_T = 0, opt_tf_raw = 0;
+  int opt_kernel = 0, opt_slab_T = 0, opt_tf_raw = 0, opt_tile = 0;
+  int opt_wave_w = 8, opt_blk_w = 2, opt_lockstep = 0;
   int last_kernel = 0;
   float last_ms = 0;
   double last_alg_bytes = 0;
@@ -127,3 +131,7 @@ struct smk_ctx {
 // launchers (one translation unit per kernel family)
 hipError_t smk_launch_gather(const RenderParams &P, int dtype, int tf_mode, int shade_kind,
                              hipStream_t s);
+// returns hipErrorNotSupported (and *why) when the frame must use the gather kernel
+hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T, int opt_tile,
+                           const void *vox_native, const void *vox_xmajor, const char **why,
+                           hipStream_t s);

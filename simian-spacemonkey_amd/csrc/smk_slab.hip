@@ -1,0 +1,499 @@
+// smk_slab.hip -- kernel S: the slice-ring ray-marcher (the fast path for 2-D / separable
+// classification without perturbation).
+//
+// Idea.  The gather kernel (smk_gather.hip) pulls 8 corners per sample through TA/L1: every
+// 128-B line is re-requested from L2 several times and waves spend ~87 % of their time in
+// s_waitcnt (profiles/r01_*).  Here the volume is streamed instead:
+//
+//   * the principal axis S of the view (largest |ray direction| component in voxel space) is
+//     chosen on the host; U is the memory-contiguous axis, V the third one;
+//   * a workgroup owns a TW x TH pixel tile: NT consumer lanes (one lane = one ray, a wave = a
+//     compact 8x8 sub-tile) plus ONE loader wave;
+//   * the workgroup walks the S-slices of the volume front to back.  The loader wave copies,
+//     one group of slices ahead, just the (u,v) window the tile's ray bundle crosses -- whole
+//     contiguous row pieces, 16 B per lane -- from HBM straight into an LDS ring slot with
+//     LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, and the consumers' own
+//     transfer-function gathers never wait behind it because vmcnt is per wave);
+//   * every consumer ray takes the samples whose base slice is resident, reading its 8 corners
+//     from LDS (ds_read_b128 / b64);
+//   * RGBA stays in registers front to back; 16 B per pixel leave the kernel.
+//
+// Each voxel row piece a tile needs is read once per tile; neighbouring tiles share only the
+// 1-3 voxel fringe (served by the XCD's L2 because tiles are dealt to XCDs in contiguous runs).
+//
+// Sample placement, membership and interpolation order are EXACTLY those of the gather kernel
+// (same fma chains), so the two kernels and the CPU checker agree bit for bit on positions.
+// Reference semantics: see smk_device.h.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "smk_device.h"
+
+// wave-uniform description of one launch
+struct SlabParams {
+  int perm;                    // 0: S=z (U=x,V=y)  1: S=y (U=x,V=z)  2: S=x (U=y,V=z; x-major copy)
+  int au, av, as;              // model-axis index of U, V, S
+  long long strideV, strideS;  // voxel strides of the layout in use (U stride is 1)
+  int Ou, Ov, Os;              // stored-box origin along U,V,S (global voxel index)
+  int Du, Dv, Ds;              // stored-box dims along U,V,S
+  int slot_vox;                // LDS voxels per ring slot (multiple of 64 DMA lanes' worth)
+  int T;                       // base slices consumed per group
+  int nslots;                  // ring size = 2*T+1
+  int dir;                     // +1: rays advance towards +S, -1: towards -S
+  int tw, th;                  // pixel tile
+  const void *vox;             // layout base (native or x-major)
+};
+
+#define SLAB_EPS 0.02f
+
+template <int DT>
+struct VoxT;
+template <>
+struct VoxT<0> {
+  typedef uint2 type;
+};
+template <>
+struct VoxT<1> {
+  typedef float4 type;
+};
+
+template <int DT>
+__device__ __forceinline__ SmkCorner slab_corner(const typename VoxT<DT>::type &v) {
+  SmkCorner k;
+  if (DT == 0) {
+    const uint2 &q = reinterpret_cast<const uint2 &>(v);
+    k.c0 = smk_ub(q.x, 0);
+    k.c1 = smk_ub(q.x, 1);
+    k.c2 = smk_ub(q.x, 2);
+    k.c3 = smk_ub(q.x, 3);
+    k.nb = q.y;
+  } else {
+    const float4 &q = reinterpret_cast<const float4 &>(v);
+    k.c0 = q.x;
+    k.c1 = q.y;
+    k.c2 = q.z;
+    k.c3 = 0.0f;
+    k.nb = __float_as_uint(q.w);
+  }
+  return k;
+}
+
+// window of one slice for this tile, in stored-box voxel coordinates; the slot holds it flat,
+// row-major with pitch w (so one DMA wave-instruction = 64 consecutive 16-byte units)
+struct SlabWin {
+  short u0, v0, w, h;
+};
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+
+// NT = consumer threads (rays); the block has NT + 64 threads, the last wave is the loader
+template <int DT, int SH, int PERM, int NT>
+__global__ __launch_bounds__(NT + 64) void smk_k_slab(const RenderParams P, const SlabParams Q) {
+  typedef typename VoxT<DT>::type Vox;
+  constexpr int UPV = DT == 0 ? 2 : 1;  // voxels per 16-byte DMA unit
+  extern __shared__ __align__(16) unsigned char smem[];
+  // LDS carve: ring [nslots][slot_vox] voxels | window table [Ds] | reduction scratch
+  Vox *ring = reinterpret_cast<Vox *>(smem);
+  const int slot_vox = Q.slot_vox;
+  SlabWin *wtab = reinterpret_cast<SlabWin *>(smem + (size_t)Q.nslots * slot_vox * sizeof(Vox));
+  int *red = reinterpret_cast<int *>(wtab + Q.Ds);
+
+  int tx, ty;
+  if (!smk_tile_of_block(P, blockIdx.x, tx, ty)) return;  // whole workgroup leaves together
+
+  const int tid = threadIdx.x;
+  const bool is_loader = tid >= NT;
+  const int lane = tid & 63, wave = tid >> 6;
+  // consumer wave = 8x8 pixel sub-tile; waves laid out row-major over the tile
+  const int wpr = Q.tw >> 3;
+  const int i = tx * Q.tw + (wave % wpr) * 8 + (lane & 7);
+  const int j = ty * Q.th + (wave / wpr) * 8 + (lane >> 3);
+  const bool live = !is_loader && i < P.W && j < P.H;
+
+  const smk_raycoef &rc = P.rc;
+  const float px = __fmaf_rn((float)i + 0.5f, rc.pxs, rc.pxl);
+  const float py = __fmaf_rn((float)j + 0.5f, rc.pys, rc.pyl);
+  float A[3], B[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    A[a] = __fmaf_rn(px, rc.Ax[a], __fmaf_rn(py, rc.Ay[a], rc.Ac[a]));
+    B[a] = __fmaf_rn(px, rc.Bx[a], __fmaf_rn(py, rc.By[a], rc.Bc[a]));
+  }
+  // conservative plane range (identical to the gather kernel)
+  float tenter = 0.0f, texit = (float)(rc.nplanes - 1);
+  bool empty = rc.nplanes <= 0 || !live;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    if (fabsf(B[a]) > 1e-20f) {
+      float inv = 1.0f / B[a];
+      float t1 = (P.lo[a] - A[a]) * inv, t2 = (P.hi[a] - A[a]) * inv;
+      tenter = fmaxf(tenter, fminf(t1, t2) - 2.0f);
+      texit = fminf(texit, fmaxf(t1, t2) + 2.0f);
+    } else if (!(A[a] >= P.lo[a] && A[a] <= P.hi[a])) {
+      empty = true;
+    }
+  }
+  int m = (int)floorf(fmaxf(tenter, 0.0f));
+  int m1 = (int)ceilf(fminf(texit, (float)(rc.nplanes - 1)));
+  if (empty || !(tenter <= texit)) m1 = m - 1;
+
+  constexpr int AS = PERM == 0 ? 2 : (PERM == 1 ? 1 : 0);
+  constexpr int AU = PERM == 2 ? 1 : 0;
+  constexpr int AV = PERM == 0 ? 1 : 2;
+  const int NS = P.N[AS], NU = P.N[AU], NV = P.N[AV];
+
+  // base slice index of plane q on this ray (a sample reads slices i0 and i0+1)
+  auto base_slice = [&](int q) -> int {
+    float s = __fmaf_rn((float)q, B[AS], A[AS]);
+    float sc = fminf(fmaxf(s, 0.0f), (float)(NS - 1));
+    return min((int)sc, NS - 2);
+  };
+
+  // ---- workgroup slice range
+  if (tid == 0) {
+    red[0] = 0x7fffffff;
+    red[1] = -0x7fffffff;
+  }
+  __syncthreads();
+  {
+    int lo = 0x7fffffff, hi = -0x7fffffff;
+    if (m <= m1) {
+      int a0 = base_slice(m), a1 = base_slice(m1);
+      lo = min(a0, a1);
+      hi = max(a0, a1);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      lo = min(lo, __shfl_xor(lo, o));
+      hi = max(hi, __shfl_xor(hi, o));
+    }
+    if (lane == 0 && lo <= hi) {
+      atomicMin(&red[0], lo);
+      atomicMax(&red[1], hi);
+    }
+  }
+  // ---- per-slice windows of this tile (every thread fills some table entries): bbox over the
+  // tile's 4 corner rays of every position a sample touching slice sl can have (s in
+  // [sl-1, sl+1], stretched to the volume faces at the ends)
+  {
+    float cA[4][3], cB[4][3];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      int ci = min(tx * Q.tw + ((c & 1) ? Q.tw - 1 : 0), P.W - 1);
+      int cj = min(ty * Q.th + ((c & 2) ? Q.th - 1 : 0), P.H - 1);
+      float cx = __fmaf_rn((float)ci + 0.5f, rc.pxs, rc.pxl), cy = __fmaf_rn((float)cj + 0.5f, rc.pys, rc.pyl);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        cA[c][a] = __fmaf_rn(cx, rc.Ax[a], __fmaf_rn(cy, rc.Ay[a], rc.Ac[a]));
+        cB[c][a] = __fmaf_rn(cx, rc.Bx[a], __fmaf_rn(cy, rc.By[a], rc.Bc[a]));
+      }
+    }
+    for (int e = tid; e < Q.Ds; e += NT + 64) {
+      int sl = Q.Os + e;  // global slice index
+      float s_lo = sl <= 1 ? -0.5f : (float)(sl - 1), s_hi = sl >= NS - 2 ? (float)NS - 0.5f : (float)(sl + 1);
+      float umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float ib = 1.0f / cB[c][AS];
+        float ma = (s_lo - cA[c][AS]) * ib, mb = (s_hi - cA[c][AS]) * ib;
+        float ua = __fmaf_rn(ma, cB[c][AU], cA[c][AU]), ub = __fmaf_rn(mb, cB[c][AU], cA[c][AU]);
+        float va = __fmaf_rn(ma, cB[c][AV], cA[c][AV]), vb = __fmaf_rn(mb, cB[c][AV], cA[c][AV]);
+        umin = fminf(umin, fminf(ua, ub));
+        umax = fmaxf(umax, fmaxf(ua, ub));
+        vmin = fminf(vmin, fminf(va, vb));
+        vmax = fmaxf(vmax, fmaxf(va, vb));
+      }
+      // texel pair of coordinate x is floor(clamp(x)), +1; SLAB_EPS absorbs fp differences
+      // between this bbox and the per-sample chains
+      int u0 = (int)floorf(fminf(fmaxf(umin - SLAB_EPS, 0.0f), (float)(NU - 2)));
+      int u1 = (int)floorf(fminf(fmaxf(umax + SLAB_EPS, 0.0f), (float)(NU - 2))) + 1;
+      int v0 = (int)floorf(fminf(fmaxf(vmin - SLAB_EPS, 0.0f), (float)(NV - 2)));
+      int v1 = (int)floorf(fminf(fmaxf(vmax + SLAB_EPS, 0.0f), (float)(NV - 2))) + 1;
+      // to stored-box coordinates, clipped to it; rows made of whole 16-byte units
+      u0 = max(u0 - Q.Ou, 0);
+      v0 = max(v0 - Q.Ov, 0);
+      u1 = min(u1 - Q.Ou, Q.Du - 1);
+      v1 = min(v1 - Q.Ov, Q.Dv - 1);
+      if (UPV == 2) {
+        u0 &= ~1;
+        u1 |= 1;  // the stored U extent is padded to an even count by the host check
+      }
+      int w = max(u1 - u0 + 1, 0), h = max(v1 - v0 + 1, 0);
+      if (w * h > slot_vox) h = w > 0 ? slot_vox / w : 0;  // never overrun a slot (host sizes it)
+      SlabWin ww;
+      ww.u0 = (short)u0;
+      ww.v0 = (short)v0;
+      ww.w = (short)w;
+      ww.h = (short)h;
+      wtab[e] = ww;
+    }
+  }
+  __syncthreads();
+  const int smin = red[0], smax = red[1];
+  float C0 = 0.f, C1 = 0.f, C2 = 0.f, C3 = 0.f;
+  float first = __int_as_float(0x7f800000);
+
+  if (smin <= smax) {  // uniform over the workgroup
+    const int dir = Q.dir, T = Q.T, nslots = Q.nslots;
+    // groups of T base slices, in marching order:
+    //   dir>0: group g = [smin + g*T, +T)  reads slices up to +T
+    //   dir<0: group g = (smax - g*T - T, smax - g*T]  reads one slice above
+    const int ngroups = (smax - smin) / T + 1;
+    const int lo0 = dir > 0 ? smin : smax - T + 1;  // lowest slice of group 0's T+1 slices
+
+    if (is_loader) {
+      // ================================ loader wave: LDS-DMA, one group ahead ==================
+      const Vox *gv = reinterpret_cast<const Vox *>(Q.vox);
+      auto dma_slice = [&](int slice) {
+        int sl = slice - Q.Os;
+        if (sl < 0 || sl >= Q.Ds) return;
+        const SlabWin w = wtab[sl];
+        const int wu = w.w / UPV;         // 16-byte units per window row
+        const int n = wu * w.h;           // units in the window
+        const float inv = 1.0f / (float)max(wu, 1);
+        Vox *dst = ring + (size_t)(slice % nslots) * slot_vox;
+        const Vox *src = gv + (size_t)sl * Q.strideS + (size_t)w.v0 * Q.strideV + (size_t)w.u0;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+          int idx = c0 + lane;
+          if (idx < n) {
+            int row = (int)(((float)idx + 0.5f) * inv);
+            int col = idx - row * wu;
+            const Vox *g = src + (size_t)row * Q.strideV + col * UPV;
+            // LDS address = wave-uniform base + lane*16: the slot image is flat in unit order
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(dst + c0 * UPV), 16, 0, 0);
+          }
+        }
+      };
+      for (int t = 0; t <= T; ++t) dma_slice(lo0 + t);
+      __syncthreads();  // (drains the DMA: hipcc waits vmcnt(0) before the barrier)
+      for (int g = 0; g < ngroups; ++g) {
+        const int blo = dir > 0 ? smin + g * T : smax - g * T - T + 1;
+        const int nxt = dir > 0 ? blo + T + 1 : blo - T;
+        if (g + 1 < ngroups)
+          for (int t = 0; t < T; ++t) dma_slice(nxt + t);
+        __syncthreads();
+      }
+    } else {
+      // ================================ consumer waves ==========================================
+      __syncthreads();
+      int bs = (m <= m1) ? base_slice(m) : -0x40000000;
+      for (int g = 0; g < ngroups; ++g) {
+        const int blo = dir > 0 ? smin + g * T : smax - g * T - T + 1;
+        const int bhi = blo + T - 1;
+        // ---- all samples of this ray whose base slice lies in [blo, bhi]
+        while (true) {
+          const bool act = bs >= blo && bs <= bhi;
+          if (!__any(act)) break;
+          if (act) {
+            float p[3];
+            p[0] = __fmaf_rn((float)m, B[0], A[0]);
+            p[1] = __fmaf_rn((float)m, B[1], A[1]);
+            p[2] = __fmaf_rn((float)m, B[2], A[2]);
+            bool in = (p[0] >= P.lo[0] && (p[0] < P.hi[0] || (P.top[0] && p[0] <= P.hi[0]))) &&
+                      (p[1] >= P.lo[1] && (p[1] < P.hi[1] || (P.top[1] && p[1] <= P.hi[1]))) &&
+                      (p[2] >= P.lo[2] && (p[2] < P.hi[2] || (P.top[2] && p[2] <= P.hi[2])));
+            if (in) {
+              int x0, x1, y0, y1, z0, z1;
+              float fx, fy, fz;
+              smk_lin_clamp(p[0], P.N[0], x0, x1, fx);
+              smk_lin_clamp(p[1], P.N[1], y0, y1, fy);
+              smk_lin_clamp(p[2], P.N[2], z0, z1, fz);
+              const int iu = (AU == 0 ? x0 : y0) - Q.Ou, iv = (AV == 1 ? y0 : z0) - Q.Ov;
+              const int is = (AS == 2 ? z0 : (AS == 1 ? y0 : x0));
+              const SlabWin wa = wtab[is - Q.Os], wb = wtab[is + 1 - Q.Os];
+              // clamp into the resident windows (never alters a result: windows cover the bundle)
+              const int ca = min(max(iu - wa.u0, 0), wa.w - 2), ra = min(max(iv - wa.v0, 0), wa.h - 2);
+              const int cb = min(max(iu - wb.u0, 0), wb.w - 2), rb = min(max(iv - wb.v0, 0), wb.h - 2);
+              const Vox *sa = ring + (size_t)(is % nslots) * slot_vox + ra * wa.w + ca;
+              const Vox *sb = ring + (size_t)((is + 1) % nslots) * slot_vox + rb * wb.w + cb;
+              // corners q[ds][dv][du]
+              SmkCorner q000 = slab_corner<DT>(sa[0]), q001 = slab_corner<DT>(sa[1]);
+              SmkCorner q010 = slab_corner<DT>(sa[wa.w]), q011 = slab_corner<DT>(sa[wa.w + 1]);
+              SmkCorner q100 = slab_corner<DT>(sb[0]), q101 = slab_corner<DT>(sb[1]);
+              SmkCorner q110 = slab_corner<DT>(sb[wb.w]), q111 = slab_corner<DT>(sb[wb.w + 1]);
+              // back to model order k<dx><dy><dz>: the lerp order (x, y, z) is the gather kernel's
+#define KX(dx, dy, dz)                                                                                   \
+  (PERM == 0 ? (dz ? (dy ? (dx ? q111 : q110) : (dx ? q101 : q100)) : (dy ? (dx ? q011 : q010) : (dx ? q001 : q000))) \
+   : PERM == 1 ? (dy ? (dz ? (dx ? q111 : q110) : (dx ? q101 : q100)) : (dz ? (dx ? q011 : q010) : (dx ? q001 : q000))) \
+               : (dx ? (dz ? (dy ? q111 : q110) : (dy ? q101 : q100)) : (dz ? (dy ? q011 : q010) : (dy ? q001 : q000))))
+              const SmkCorner &k000 = KX(0, 0, 0), &k100 = KX(1, 0, 0), &k010 = KX(0, 1, 0), &k110 = KX(1, 1, 0);
+              const SmkCorner &k001 = KX(0, 0, 1), &k101 = KX(1, 0, 1), &k011 = KX(0, 1, 1), &k111 = KX(1, 1, 1);
+#undef KX
+              const float sc = DT == 0 ? SMK_INV255 : 1.0f;
+              float ch0 = SMK_TRI(c0), ch1 = SMK_TRI(c1), ch2 = 0.f, ch3 = 0.f;
+              if (DT == 0) {
+                ch0 *= sc;
+                ch1 *= sc;
+              }
+              if (P.third_axis) {
+                ch2 = SMK_TRI(c2);
+                if (DT == 0) ch2 *= sc;
+                if (DT == 0 && P.nelts == 4) ch3 = SMK_TRI(c3) * sc;
+              }
+              float4 col;
+              if (smk_classify<DT, 1>(P, ch0, ch1, ch2, ch3, col)) {
+                float4 src;
+                if (SH == 0) {
+                  src = smk_shade_sample<0>(P, col, 0.f, 0.f, 0.f, 0.f);
+                } else {
+                  float n0 = smk_nrm(k000.nb, k100.nb, k010.nb, k110.nb, k001.nb, k101.nb, k011.nb, k111.nb, 0, fx, fy, fz);
+                  float n1 = smk_nrm(k000.nb, k100.nb, k010.nb, k110.nb, k001.nb, k101.nb, k011.nb, k111.nb, 1, fx, fy, fz);
+                  float n2 = smk_nrm(k000.nb, k100.nb, k010.nb, k110.nb, k001.nb, k101.nb, k011.nb, k111.nb, 2, fx, fy, fz);
+                  src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1);
+                }
+                float w = 1.0f - C3;
+                if (first == __int_as_float(0x7f800000)) first = __fmaf_rn((float)m, rc.dtau, rc.tau0) * P.znear;
+                C0 = __fmaf_rn(w, src.x, C0);
+                C1 = __fmaf_rn(w, src.y, C1);
+                C2 = __fmaf_rn(w, src.z, C2);
+                C3 = __fmaf_rn(w, src.w, C3);
+              }
+            }
+            ++m;
+            bs = (m <= m1) ? base_slice(m) : -0x40000000;
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+  if (live) {
+    size_t o = (size_t)j * P.W + i;
+    P.out[o] = make_float4(C0, C1, C2, C3);
+    if (P.depth) P.depth[o] = first;
+  }
+}
+
+// ------------------------------------------------------------------------------- host side
+
+static void host_ray(const RenderParams &P, int i, int j, double A[3], double B[3]) {
+  const smk_raycoef &rc = P.rc;
+  float px = fmaf((float)i + 0.5f, rc.pxs, rc.pxl), py = fmaf((float)j + 0.5f, rc.pys, rc.pyl);
+  for (int a = 0; a < 3; ++a) {
+    A[a] = fmaf(px, rc.Ax[a], fmaf(py, rc.Ay[a], rc.Ac[a]));
+    B[a] = fmaf(px, rc.Bx[a], fmaf(py, rc.By[a], rc.Bc[a]));
+  }
+}
+
+template <int DT, int SH, int PERM, int NT>
+static hipError_t launch_slab(const RenderParams &P, const SlabParams &Q, size_t lds, hipStream_t s) {
+  auto k = smk_k_slab<DT, SH, PERM, NT>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k, dim3(8 * P.tiles_per_xcd), dim3(NT + 64), lds, s, P, Q);
+  return hipGetLastError();
+}
+
+// plan + launch; returns hipErrorNotSupported when the configuration must use the gather kernel
+hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T, int opt_tile, const void *vox_native,
+                           const void *vox_xmajor, const char **why, hipStream_t s) {
+  *why = nullptr;
+  if (P.pert_on) { *why = "perturbation"; return hipErrorNotSupported; }
+  if (P.N[0] < 2 || P.N[1] < 2 || P.N[2] < 2) { *why = "volume thinner than 2 voxels"; return hipErrorNotSupported; }
+  if (dtype == 1 && !P.n_in_w) { *why = "4-channel f32 voxels"; return hipErrorNotSupported; }
+  if (P.rc.nplanes <= 0) { *why = "no planes"; return hipErrorNotSupported; }
+
+  // principal axis from the central ray
+  double Ac[3], Bc[3];
+  host_ray(P, P.W / 2, P.H / 2, Ac, Bc);
+  int as = 0;
+  for (int a = 1; a < 3; ++a)
+    if (fabs(Bc[a]) > fabs(Bc[as])) as = a;
+  SlabParams Q;
+  memset(&Q, 0, sizeof Q);
+  Q.as = as;
+  if (as == 2) { Q.perm = 0; Q.au = 0; Q.av = 1; }
+  else if (as == 1) { Q.perm = 1; Q.au = 0; Q.av = 2; }
+  else { Q.perm = 2; Q.au = 1; Q.av = 2; }
+  if (Q.perm == 2 && !vox_xmajor) { *why = "x-major copy unavailable"; return hipErrorNotSupported; }
+  Q.dir = Bc[as] > 0 ? 1 : -1;
+  Q.Ou = P.O[Q.au]; Q.Ov = P.O[Q.av]; Q.Os = P.O[as];
+  Q.Du = P.D[Q.au]; Q.Dv = P.D[Q.av]; Q.Ds = P.D[as];
+  if (Q.perm == 0) { Q.strideV = P.D[0]; Q.strideS = (long long)P.D[0] * P.D[1]; Q.vox = vox_native; }
+  else if (Q.perm == 1) { Q.strideV = (long long)P.D[0] * P.D[1]; Q.strideS = P.D[0]; Q.vox = vox_native; }
+  else { Q.strideV = P.D[1]; Q.strideS = (long long)P.D[1] * P.D[2]; Q.vox = vox_xmajor; }  // [x][z][y]
+  if (Q.Ds > 4096) { *why = "more than 4096 slices"; return hipErrorNotSupported; }
+  // u8 voxels are 8 B: the DMA moves 16-B units, so rows must start and end on even voxels
+  if (dtype == 0 && ((Q.Du & 1) || (Q.strideV & 1) || (Q.strideS & 1))) { *why = "odd U extent for 8-byte voxels"; return hipErrorNotSupported; }
+
+  // tile shape
+  int tw = 32, th = 16;
+  if (opt_tile == 1) { tw = 16; th = 16; }
+  else if (opt_tile == 2) { tw = 32; th = 32; }
+  else if (opt_tile == 3) { tw = 32; th = 8; }
+  else if (opt_tile == 4) { tw = 64; th = 8; }
+  else if (opt_tile == 5) { tw = 64; th = 16; }
+  const int nt = tw * th;
+  Q.tw = tw; Q.th = th;
+  P.ntx = (P.W + tw - 1) / tw;
+  P.nty = (P.H + th - 1) / th;
+  P.tiles_per_xcd = (P.ntx * P.nty + 7) / 8;
+
+  // every ray must advance along S in the same direction and not too obliquely; window bound:
+  // bundle cross-section extent (corner rays of every tile) at the two S faces + drift over the
+  // two-slice interval a window covers + texel pair + eps
+  double max_eu = 0, max_ev = 0, max_drift_u = 0, max_drift_v = 0;
+  const double sf[2] = {-0.5, (double)P.N[as] - 0.5};
+  for (int tyi = 0; tyi < P.nty; ++tyi)
+    for (int txi = 0; txi < P.ntx; ++txi) {
+      double umin[2] = {1e300, 1e300}, umax[2] = {-1e300, -1e300}, vmin[2] = {1e300, 1e300}, vmax[2] = {-1e300, -1e300};
+      for (int c = 0; c < 4; ++c) {
+        int ci = std::min(txi * tw + ((c & 1) ? tw - 1 : 0), P.W - 1);
+        int cj = std::min(tyi * th + ((c & 2) ? th - 1 : 0), P.H - 1);
+        double A[3], B[3];
+        host_ray(P, ci, cj, A, B);
+        if (!(B[as] * Q.dir > 0) || fabs(B[as]) < 1e-12) { *why = "rays do not share a marching direction"; return hipErrorNotSupported; }
+        double du = fabs(B[Q.au] / B[as]), dv = fabs(B[Q.av] / B[as]);
+        if (du > 1.5 || dv > 1.5) { *why = "view too oblique for the principal axis"; return hipErrorNotSupported; }
+        max_drift_u = std::max(max_drift_u, du);
+        max_drift_v = std::max(max_drift_v, dv);
+        for (int f = 0; f < 2; ++f) {
+          double mm = (sf[f] - A[as]) / B[as];
+          double u = A[Q.au] + B[Q.au] * mm, v = A[Q.av] + B[Q.av] * mm;
+          umin[f] = std::min(umin[f], u); umax[f] = std::max(umax[f], u);
+          vmin[f] = std::min(vmin[f], v); vmax[f] = std::max(vmax[f], v);
+        }
+      }
+      for (int f = 0; f < 2; ++f) {
+        max_eu = std::max(max_eu, umax[f] - umin[f]);
+        max_ev = std::max(max_ev, vmax[f] - vmin[f]);
+      }
+    }
+  // a window spans s in [j-1, j+1] (2 slices of drift; 2.5 at the faces), + pair + eps + rounding
+  int Wu = (int)ceil(max_eu + 2.5 * max_drift_u + 2 * SLAB_EPS) + 3;
+  int Wv = (int)ceil(max_ev + 2.5 * max_drift_v + 2 * SLAB_EPS) + 3;
+  if (dtype == 0) Wu += 2;  // even alignment of both ends
+  Wu = std::min(Wu, Q.Du);
+  Wv = std::min(Wv, Q.Dv);
+  if (Wu < 2 || Wv < 2) { *why = "degenerate window"; return hipErrorNotSupported; }
+  if (Wu > 32000 || Wv > 32000) { *why = "window too large"; return hipErrorNotSupported; }
+  const int upv = dtype == 0 ? 2 : 1;
+  Q.slot_vox = ((Wu * Wv + 64 * upv - 1) / (64 * upv)) * (64 * upv);
+
+  const size_t vb = dtype == 0 ? 8 : 16;
+  int T = opt_T > 0 ? opt_T : 2;
+  for (;; --T) {
+    if (T < 1) { *why = "window does not fit LDS"; return hipErrorNotSupported; }
+    Q.T = T;
+    Q.nslots = 2 * T + 1;
+    size_t lds = (size_t)Q.nslots * Q.slot_vox * vb + (size_t)Q.Ds * sizeof(SlabWin) + 64;
+    if (lds <= 158 * 1024) {
+#define GO(D, S, R, N) \
+  if (dtype == D && shade_kind == S && Q.perm == R && nt == N) return launch_slab<D, S, R, N>(P, Q, lds, s);
+#define GO_NT(D, S, R) GO(D, S, R, 256) GO(D, S, R, 512)
+#define GO_R(D, S) GO_NT(D, S, 0) GO_NT(D, S, 1) GO_NT(D, S, 2)
+      GO_R(0, 0) GO_R(0, 1) GO_R(0, 2) GO_R(1, 0) GO_R(1, 1) GO_R(1, 2)
+#undef GO_R
+#undef GO_NT
+#undef GO
+      *why = "no kernel instance for this tile size";
+      return hipErrorNotSupported;
+    }
+  }
+}
