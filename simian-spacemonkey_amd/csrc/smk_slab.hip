@@ -7,15 +7,18 @@
 //
 //   * the principal axis S of the view (largest |ray direction| component in voxel space) is
 //     chosen on the host; U is the memory-contiguous axis, V the third one;
-//   * a workgroup owns a TW x TH pixel tile: NT consumer lanes (one lane = one ray, a wave = a
+//   * a workgroup owns a TW x TH pixel tile: NW consumer waves (one lane = one ray, a wave = a
 //     compact 8x8 sub-tile) plus ONE loader wave;
-//   * the workgroup walks the S-slices of the volume front to back.  The loader wave copies,
-//     one group of slices ahead, just the (u,v) window the tile's ray bundle crosses -- whole
-//     contiguous row pieces, 16 B per lane -- from HBM straight into an LDS ring slot with
-//     LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, and the consumers' own
-//     transfer-function gathers never wait behind it because vmcnt is per wave);
-//   * every consumer ray takes the samples whose base slice is resident, reading its 8 corners
-//     from LDS (ds_read_b128 / b64);
+//   * the loader wave streams, front to back, the (u,v) window of every S-slice the tile's ray
+//     bundle crosses -- whole contiguous row pieces, 16 B per lane -- from HBM straight into
+//     an LDS ring with LDS-DMA (global_load_lds_dwordx4: no VGPR round trip).  It keeps
+//     several slices in flight behind a COUNTED s_waitcnt vmcnt(N) and publishes a `landed`
+//     counter; the consumers' transfer-function gathers never wait behind the stream because
+//     vmcnt is per wave;
+//   * every consumer wave advances on its own (no workgroup barrier in the main loop): it
+//     waits for `landed`, takes the samples whose base slice is resident, reading the 8
+//     corners from LDS (ds_read_b128 / b64), and publishes its progress; the loader reuses a
+//     ring slot once every wave is past it;
 //   * RGBA stays in registers front to back; 16 B per pixel leave the kernel.
 //
 // Each voxel row piece a tile needs is read once per tile; neighbouring tiles share only the
@@ -38,15 +41,19 @@ struct SlabParams {
   long long strideV, strideS;  // voxel strides of the layout in use (U stride is 1)
   int Ou, Ov, Os;              // stored-box origin along U,V,S (global voxel index)
   int Du, Dv, Ds;              // stored-box dims along U,V,S
-  int slot_vox;                // LDS voxels per ring slot (multiple of 64 DMA lanes' worth)
-  int T;                       // base slices consumed per group
-  int nslots;                  // ring size = 2*T+1
+  int slot_vox;                // LDS voxels per ring slot (a whole number of 64-lane DMA chunks)
+  int chunks;                  // DMA wave-instructions per slice (= slot_vox / (64*UPV)), uniform
+  int gmax;                    // base slices a consumer may take per step
+  int nslots;                  // ring size
+  int maxfly;                  // slices the loader keeps in flight (chunks*(maxfly-1) <= 63)
   int dir;                     // +1: rays advance towards +S, -1: towards -S
   int tw, th;                  // pixel tile
   const void *vox;             // layout base (native or x-major)
+  int use_ah;                  // third-axis alpha served from a 1-D LDS table (<= 3 channels)
 };
 
 #define SLAB_EPS 0.02f
+#define SLAB_DONE 0x3fffffff
 
 template <int DT>
 struct VoxT;
@@ -83,30 +90,92 @@ __device__ __forceinline__ SmkCorner slab_corner(const typename VoxT<DT>::type &
 // window of one slice for this tile, in stored-box voxel coordinates; the slot holds it flat,
 // row-major with pitch w (so one DMA wave-instruction = 64 consecutive 16-byte units)
 struct SlabWin {
-  short u0, v0, w, h;
+  short u0, v0;
+  unsigned char w, h;  // window dims (<= 255, host-checked)
+  short slot;          // ring slot of the slice
 };
+
+// one LDS voxel read as a single ds_read_b128 / b64: the empty asm keeps hipcc from splitting
+// the vector load into partial ds_read2_b32 pieces per consumer
+__device__ __forceinline__ float4 lds_vox(const float4 *p) {
+  float4 v = *p;
+  asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+  return v;
+}
+__device__ __forceinline__ uint2 lds_vox(const uint2 *p) {
+  uint2 v = *p;
+  asm volatile("" : "+v"(v.x), "+v"(v.y));
+  return v;
+}
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 
-// NT = consumer threads (rays); the block has NT + 64 threads, the last wave is the loader
-template <int DT, int SH, int PERM, int NT>
-__global__ __launch_bounds__(NT + 64) void smk_k_slab(const RenderParams P, const SlabParams Q) {
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    W(0) W(1) W(2) W(3) W(4) W(5) W(6) W(7) W(8) W(9) W(10) W(11) W(12) W(13) W(14) W(15)
+    W(16) W(17) W(18) W(19) W(20) W(21) W(22) W(23) W(24) W(25) W(26) W(27) W(28) W(29) W(30) W(31)
+    W(32) W(33) W(34) W(35) W(36) W(37) W(38) W(39) W(40) W(41) W(42) W(43) W(44) W(45) W(46) W(47)
+    W(48) W(49) W(50) W(51) W(52) W(53) W(54) W(55) W(56) W(57) W(58) W(59) W(60) W(61) W(62) W(63)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef W
+}
+
+__device__ __forceinline__ int lds_ld(const int *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_st(int *p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// LDS reads of the LOADER wave go through inline asm: with an LDS-DMA in flight hipcc puts
+// s_waitcnt vmcnt(0) in front of every LDS read it can see (it cannot prove the read does not
+// alias the DMA destination), which would drain the whole stream once per loop iteration.
+// (cdna_hip_programming.md 5.7: the wait for an asm load is ours to place -- it is in the string.)
+typedef __attribute__((address_space(3))) const void *lds_cptr_t;
+__device__ __forceinline__ int raw_lds_b32(const void *p) {
+  int v;
+  unsigned a = (unsigned)(size_t)(lds_cptr_t)p;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint2 raw_lds_b64(const void *p) {
+  uint2 v;
+  unsigned a = (unsigned)(size_t)(lds_cptr_t)p;
+  asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+  return v;
+}
+
+__device__ __forceinline__ void raw_lds_st_b32(void *p, int v) {
+  unsigned a = (unsigned)(size_t)(lds_cptr_t)p;
+  asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
+}
+
+// NW = consumer waves (64 rays each); the block has (NW+1)*64 threads, the last wave is the loader
+template <int DT, int SH, int PERM, int NW>
+__global__ __launch_bounds__((NW + 1) * 64) void smk_k_slab(const RenderParams P, const SlabParams Q) {
   typedef typename VoxT<DT>::type Vox;
   constexpr int UPV = DT == 0 ? 2 : 1;  // voxels per 16-byte DMA unit
+  constexpr int NTH = (NW + 1) * 64;
   extern __shared__ __align__(16) unsigned char smem[];
-  // LDS carve: ring [nslots][slot_vox] voxels | window table [Ds] | reduction scratch
+  // LDS carve: ring [nslots][slot_vox] voxels | window table [Ds] | control words | alpha_H
   Vox *ring = reinterpret_cast<Vox *>(smem);
   const int slot_vox = Q.slot_vox;
   SlabWin *wtab = reinterpret_cast<SlabWin *>(smem + (size_t)Q.nslots * slot_vox * sizeof(Vox));
-  int *red = reinterpret_cast<int *>(wtab + Q.Ds);
+  int *ctl = reinterpret_cast<int *>(wtab + Q.Ds);  // [0] smin [1] smax [2] landed [4..4+NW) progress
+  // third-axis alpha as a 1-D table: with <= 3 channels the (H,4th) lookup has t = 0, i.e. row
+  // 0 of deptex2 with a zero t-weight, so lerp(row0[s0], row0[s1], fs) is the SAME float
+  float *ah = reinterpret_cast<float *>(ctl + 4 + 32);
 
   int tx, ty;
   if (!smk_tile_of_block(P, blockIdx.x, tx, ty)) return;  // whole workgroup leaves together
 
   const int tid = threadIdx.x;
-  const bool is_loader = tid >= NT;
   const int lane = tid & 63, wave = tid >> 6;
+  const bool is_loader = wave == NW;
   // consumer wave = 8x8 pixel sub-tile; waves laid out row-major over the tile
   const int wpr = Q.tw >> 3;
   const int i = tx * Q.tw + (wave % wpr) * 8 + (lane & 7);
@@ -154,9 +223,12 @@ __global__ __launch_bounds__(NT + 64) void smk_k_slab(const RenderParams P, cons
 
   // ---- workgroup slice range
   if (tid == 0) {
-    red[0] = 0x7fffffff;
-    red[1] = -0x7fffffff;
+    ctl[0] = 0x7fffffff;
+    ctl[1] = -0x7fffffff;
+    ctl[2] = 0;
+    ctl[3] = 0;  // protocol time-out flag (bounded spins)
   }
+  if (tid < 32) ctl[4 + tid] = SLAB_DONE;
   __syncthreads();
   {
     int lo = 0x7fffffff, hi = -0x7fffffff;
@@ -170,14 +242,20 @@ __global__ __launch_bounds__(NT + 64) void smk_k_slab(const RenderParams P, cons
       hi = max(hi, __shfl_xor(hi, o));
     }
     if (lane == 0 && lo <= hi) {
-      atomicMin(&red[0], lo);
-      atomicMax(&red[1], hi);
+      atomicMin(&ctl[0], lo);
+      atomicMax(&ctl[1], hi);
     }
   }
+  __syncthreads();
+  const int smin = ctl[0], smax = ctl[1];
+  const int dir = Q.dir, nslots = Q.nslots;
+  // positions p = 0..npos-1 in marching order: base slice b(p) = dir>0 ? smin+p : smax-p;
+  // load order q = 0..npos: slice L(q) = dir>0 ? smin+q : smax+1-q; position p reads L(p), L(p+1)
+  const int npos = smax - smin + 1;
   // ---- per-slice windows of this tile (every thread fills some table entries): bbox over the
   // tile's 4 corner rays of every position a sample touching slice sl can have (s in
   // [sl-1, sl+1], stretched to the volume faces at the ends)
-  {
+  if (npos > 0) {
     float cA[4][3], cB[4][3];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -190,8 +268,12 @@ __global__ __launch_bounds__(NT + 64) void smk_k_slab(const RenderParams P, cons
         cB[c][a] = __fmaf_rn(cx, rc.Bx[a], __fmaf_rn(cy, rc.By[a], rc.Bc[a]));
       }
     }
-    for (int e = tid; e < Q.Ds; e += NT + 64) {
-      int sl = Q.Os + e;  // global slice index
+    if (Q.use_ah)
+      for (int e = tid; e < P.sv; e += NTH) ah[e] = smk_ub(P.tf_h[e], 3);
+    for (int q = tid; q <= npos; q += NTH) {
+      int sl = dir > 0 ? smin + q : smax + 1 - q;  // global slice index
+      int e = sl - Q.Os;
+      if (e < 0 || e >= Q.Ds) continue;
       float s_lo = sl <= 1 ? -0.5f : (float)(sl - 1), s_hi = sl >= NS - 2 ? (float)NS - 0.5f : (float)(sl + 1);
       float umin = 1e30f, umax = -1e30f, vmin = 1e30f, vmax = -1e30f;
 #pragma unroll
@@ -218,82 +300,178 @@ __global__ __launch_bounds__(NT + 64) void smk_k_slab(const RenderParams P, cons
       v1 = min(v1 - Q.Ov, Q.Dv - 1);
       if (UPV == 2) {
         u0 &= ~1;
-        u1 |= 1;  // the stored U extent is padded to an even count by the host check
+        u1 |= 1;  // the stored U extent is even (host check)
       }
       int w = max(u1 - u0 + 1, 0), h = max(v1 - v0 + 1, 0);
       if (w * h > slot_vox) h = w > 0 ? slot_vox / w : 0;  // never overrun a slot (host sizes it)
       SlabWin ww;
       ww.u0 = (short)u0;
       ww.v0 = (short)v0;
-      ww.w = (short)w;
-      ww.h = (short)h;
+      ww.w = (unsigned char)w;
+      ww.h = (unsigned char)h;
+      ww.slot = (short)(q % nslots);
       wtab[e] = ww;
     }
   }
-  __syncthreads();
-  const int smin = red[0], smax = red[1];
+  // every consumer wave announces the first position it needs before anyone moves on
+  int bs = (m <= m1) ? base_slice(m) : -0x40000000;
+  auto pos_of = [&](int b) -> int { return dir > 0 ? b - smin : smax - b; };
+  int pos = SLAB_DONE;
+  if (!is_loader && npos > 0) {
+    int p0 = (m <= m1) ? pos_of(bs) : SLAB_DONE;
+    for (int o = 32; o > 0; o >>= 1) p0 = min(p0, __shfl_xor(p0, o));
+    pos = p0;
+    if (lane == 0) ctl[4 + wave] = pos;
+  }
+  __syncthreads();  // table, alpha_H, control words visible; LAST workgroup barrier
   float C0 = 0.f, C1 = 0.f, C2 = 0.f, C3 = 0.f;
   float first = __int_as_float(0x7f800000);
 
-  if (smin <= smax) {  // uniform over the workgroup
-    const int dir = Q.dir, T = Q.T, nslots = Q.nslots;
-    // groups of T base slices, in marching order:
-    //   dir>0: group g = [smin + g*T, +T)  reads slices up to +T
-    //   dir<0: group g = (smax - g*T - T, smax - g*T]  reads one slice above
-    const int ngroups = (smax - smin) / T + 1;
-    const int lo0 = dir > 0 ? smin : smax - T + 1;  // lowest slice of group 0's T+1 slices
-
+  if (npos > 0) {
     if (is_loader) {
-      // ================================ loader wave: LDS-DMA, one group ahead ==================
-      const Vox *gv = reinterpret_cast<const Vox *>(Q.vox);
-      auto dma_slice = [&](int slice) {
-        int sl = slice - Q.Os;
-        if (sl < 0 || sl >= Q.Ds) return;
-        const SlabWin w = wtab[sl];
-        const int wu = w.w / UPV;         // 16-byte units per window row
-        const int n = wu * w.h;           // units in the window
-        const float inv = 1.0f / (float)max(wu, 1);
-        Vox *dst = ring + (size_t)(slice % nslots) * slot_vox;
-        const Vox *src = gv + (size_t)sl * Q.strideS + (size_t)w.v0 * Q.strideV + (size_t)w.u0;
-        for (int c0 = 0; c0 < n; c0 += 64) {
-          int idx = c0 + lane;
-          if (idx < n) {
-            int row = (int)(((float)idx + 0.5f) * inv);
-            int col = idx - row * wu;
-            const Vox *g = src + (size_t)row * Q.strideV + col * UPV;
-            // LDS address = wave-uniform base + lane*16: the slot image is flat in unit order
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(dst + c0 * UPV), 16, 0, 0);
-          }
-        }
+      // ================================ loader wave ============================================
+      // Streams load indices q = 0..npos in order.  Slot of q is q % nslots; it may be rewritten
+      // once every consumer is past position q - nslots (positions < min progress are done).
+      // Every slice issues exactly `chunks` DMA instructions (lanes past the window re-read
+      // the window's first unit into the slot's unused tail), so the in-order vmcnt tells
+      // which slices have landed: `inflight` slices outstanding <=> vmcnt <= chunks*inflight.
+      __builtin_amdgcn_s_setprio(3);  // the stream must never wait for issue slots behind pollers
+      const char *gv = reinterpret_cast<const char *>(Q.vox);
+      const int chunks = Q.chunks;
+      const unsigned strideVb = (unsigned)(Q.strideV * (long long)sizeof(Vox));  // bytes, < 2^32
+      int q = 0, inflight = 0, landed = 0, idle = 0, minp = 0;
+      long long t_issue = 0, t_wait = 0, t_idle = 0, t_all = __builtin_amdgcn_s_memtime(), t0_ = 0;
+      const bool prof = (P.lockstep & 4) != 0;  // (diagnostic build switch: loader cycle shares)
+      auto poll_progress = [&]() -> int {
+        int v = SLAB_DONE;
+        if (lane < NW) v = raw_lds_b32(&ctl[4 + lane]);
+        for (int o = 16; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+        return __builtin_amdgcn_readfirstlane(v);
       };
-      for (int t = 0; t <= T; ++t) dma_slice(lo0 + t);
-      __syncthreads();  // (drains the DMA: hipcc waits vmcnt(0) before the barrier)
-      for (int g = 0; g < ngroups; ++g) {
-        const int blo = dir > 0 ? smin + g * T : smax - g * T - T + 1;
-        const int nxt = dir > 0 ? blo + T + 1 : blo - T;
-        if (g + 1 < ngroups)
-          for (int t = 0; t < T; ++t) dma_slice(nxt + t);
-        __syncthreads();
+      while (landed <= npos) {
+        // ---- issue while the ring has room (progress is re-polled only when it blocks us)
+        bool stop = false;
+        if (prof) t0_ = __builtin_amdgcn_s_memtime();
+        while (q <= npos && inflight < Q.maxfly) {
+          if (q - nslots >= minp) {
+            minp = poll_progress();
+            if (minp >= SLAB_DONE) {  // every consumer finished: the rest is not needed
+              stop = true;
+              break;
+            }
+            if (q - nslots >= minp) break;
+          }
+          const int sl = (dir > 0 ? smin + q : smax + 1 - q) - Q.Os;
+          if (sl >= 0 && sl < Q.Ds) {
+            SlabWin w;
+            {
+              uint2 raw = raw_lds_b64(&wtab[sl]);
+              memcpy(&w, &raw, sizeof w);
+            }
+            const int wu = max(w.w / UPV, 1);  // 16-byte units per window row
+            const int n = (w.w / UPV) * w.h;   // units in the window
+            Vox *dst = ring + w.slot * slot_vox;
+            // wave-uniform 64-bit base of the window + a 32-bit per-lane byte offset
+            // (diagnostic bit 8: every slice re-reads slice 0 -> L2-hot stream, isolates issue cost)
+            const size_t sl_src = (P.lockstep & 8) ? 0 : (size_t)sl;
+            const char *base = gv + (sl_src * Q.strideS + (size_t)w.v0 * Q.strideV + (size_t)w.u0) * sizeof(Vox);
+            // lane's unit: idx = 64*c + lane = row*wu + col, advanced incrementally per chunk
+            const int q64 = 64 / wu, r64 = 64 - q64 * wu;
+            const int row0 = lane / wu;
+            int col = lane - row0 * wu;
+            unsigned off = (unsigned)row0 * strideVb + (unsigned)col * 16u;
+            const unsigned step = (unsigned)q64 * strideVb + (unsigned)r64 * 16u;
+            const unsigned wrap = strideVb - (unsigned)wu * 16u;
+            int left = n - lane;  // > 0 while this lane's unit is inside the window
+            for (int c = 0; c < chunks; ++c) {
+              const unsigned o = left > 0 ? off : 0u;
+              // LDS address = wave-uniform base + lane*16: the slot image is flat in unit order
+              __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + o), (lds_ptr_t)(dst + c * 64 * UPV), 16, 0, 0);
+              left -= 64;
+              col += r64;
+              off += step;
+              if (col >= wu) {
+                col -= wu;
+                off += wrap;
+              }
+            }
+          } else {
+            // slice outside the stored box (never read): keep the instruction count uniform
+            for (int c = 0; c < chunks; ++c)
+              __builtin_amdgcn_global_load_lds((glb_ptr_t)gv, (lds_ptr_t)(ring + (q % nslots) * slot_vox + c * 64 * UPV), 16, 0, 0);
+          }
+          ++q;
+          ++inflight;
+        }
+        if (prof) t_issue += __builtin_amdgcn_s_memtime() - t0_;
+        if (stop) break;
+        if (inflight > 0) {
+          // retire the oldest slice in flight: all but the (inflight-1) younger slices' DMAs done
+          if (prof) t0_ = __builtin_amdgcn_s_memtime();
+          wait_vmcnt(chunks * (inflight - 1));
+          if (prof) t_wait += __builtin_amdgcn_s_memtime() - t0_;
+          --inflight;
+          ++landed;
+          raw_lds_st_b32(&ctl[2], landed);
+        } else {
+          if (prof) t_idle += 200;
+          if (++idle > (1 << 22) || raw_lds_b32(&ctl[3])) {  // bounded spin (see consumers)
+            raw_lds_st_b32(&ctl[3], 1);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      wait_vmcnt(0);
+      if (prof && lane == 0) {
+        t_all = __builtin_amdgcn_s_memtime() - t_all;
+        P.out[P.W * (size_t)P.H - 1 - blockIdx.x] = make_float4((float)t_issue, (float)t_wait, (float)t_idle, (float)t_all);
       }
     } else {
       // ================================ consumer waves ==========================================
-      __syncthreads();
-      int bs = (m <= m1) ? base_slice(m) : -0x40000000;
-      for (int g = 0; g < ngroups; ++g) {
-        const int blo = dir > 0 ? smin + g * T : smax - g * T - T + 1;
-        const int bhi = blo + T - 1;
-        // ---- all samples of this ray whose base slice lies in [blo, bhi]
+      while (pos < npos) {
+        // fast-forward to the first position any lane still has a sample in
+        int pn = (m <= m1) ? pos_of(bs) : SLAB_DONE;
+        for (int o = 32; o > 0; o >>= 1) pn = min(pn, __shfl_xor(pn, o));
+        pn = __builtin_amdgcn_readfirstlane(pn);
+        if (pn >= SLAB_DONE) break;
+        if (pn > pos) {
+          pos = pn;
+          if (lane == 0) lds_st(&ctl[4 + wave], pos);
+        }
+        // wait until the slices of position pos (load indices pos, pos+1) have landed; take up
+        // to gmax positions if more are already resident
+        int have = lds_ld(&ctl[2]);
+        for (int spins = 0; have < pos + 2; ++spins) {
+          if (spins > (1 << 22) || lds_ld(&ctl[3])) {  // bounded: never hang the GPU on a protocol bug
+            lds_st(&ctl[3], 1);
+            have = 0x3ffffff0;
+            pos = npos;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(4);
+          have = lds_ld(&ctl[2]);
+        }
+        if (pos >= npos) break;
+        have = __builtin_amdgcn_readfirstlane(have);
+        asm volatile("" ::: "memory");  // slot reads stay behind the poll
+        const int G = min(min(Q.gmax, have - pos - 1), npos - pos);
+        const int b0 = dir > 0 ? smin + pos : smax - pos - G + 1, b1 = b0 + G - 1;
+        // ---- all samples of this ray whose base slice lies in [b0, b1]
         while (true) {
-          const bool act = bs >= blo && bs <= bhi;
+          const bool act = bs >= b0 && bs <= b1 && !(P.lockstep & 2);  // (debug bit 2: stream only)
           if (!__any(act)) break;
           if (act) {
             float p[3];
             p[0] = __fmaf_rn((float)m, B[0], A[0]);
             p[1] = __fmaf_rn((float)m, B[1], A[1]);
             p[2] = __fmaf_rn((float)m, B[2], A[2]);
-            bool in = (p[0] >= P.lo[0] && (p[0] < P.hi[0] || (P.top[0] && p[0] <= P.hi[0]))) &&
-                      (p[1] >= P.lo[1] && (p[1] < P.hi[1] || (P.top[1] && p[1] <= P.hi[1]))) &&
-                      (p[2] >= P.lo[2] && (p[2] < P.hi[2] || (P.top[2] && p[2] <= P.hi[2])));
+            // same membership predicate as the gather kernel, evaluated without short-circuit
+            // branches (bitwise on lane masks)
+            const bool t0 = P.top[0] != 0, t1 = P.top[1] != 0, t2 = P.top[2] != 0;
+            bool in = ((p[0] >= P.lo[0]) & ((p[0] < P.hi[0]) | (t0 & (p[0] <= P.hi[0])))) &
+                      ((p[1] >= P.lo[1]) & ((p[1] < P.hi[1]) | (t1 & (p[1] <= P.hi[1])))) &
+                      ((p[2] >= P.lo[2]) & ((p[2] < P.hi[2]) | (t2 & (p[2] <= P.hi[2]))));
             if (in) {
               int x0, x1, y0, y1, z0, z1;
               float fx, fy, fz;
@@ -306,13 +484,13 @@ __global__ __launch_bounds__(NT + 64) void smk_k_slab(const RenderParams P, cons
               // clamp into the resident windows (never alters a result: windows cover the bundle)
               const int ca = min(max(iu - wa.u0, 0), wa.w - 2), ra = min(max(iv - wa.v0, 0), wa.h - 2);
               const int cb = min(max(iu - wb.u0, 0), wb.w - 2), rb = min(max(iv - wb.v0, 0), wb.h - 2);
-              const Vox *sa = ring + (size_t)(is % nslots) * slot_vox + ra * wa.w + ca;
-              const Vox *sb = ring + (size_t)((is + 1) % nslots) * slot_vox + rb * wb.w + cb;
+              const Vox *sa = ring + (wa.slot * slot_vox + ra * wa.w + ca);
+              const Vox *sb = ring + (wb.slot * slot_vox + rb * wb.w + cb);
               // corners q[ds][dv][du]
-              SmkCorner q000 = slab_corner<DT>(sa[0]), q001 = slab_corner<DT>(sa[1]);
-              SmkCorner q010 = slab_corner<DT>(sa[wa.w]), q011 = slab_corner<DT>(sa[wa.w + 1]);
-              SmkCorner q100 = slab_corner<DT>(sb[0]), q101 = slab_corner<DT>(sb[1]);
-              SmkCorner q110 = slab_corner<DT>(sb[wb.w]), q111 = slab_corner<DT>(sb[wb.w + 1]);
+              SmkCorner q000 = slab_corner<DT>(lds_vox(sa)), q001 = slab_corner<DT>(lds_vox(sa + 1));
+              SmkCorner q010 = slab_corner<DT>(lds_vox(sa + wa.w)), q011 = slab_corner<DT>(lds_vox(sa + wa.w + 1));
+              SmkCorner q100 = slab_corner<DT>(lds_vox(sb)), q101 = slab_corner<DT>(lds_vox(sb + 1));
+              SmkCorner q110 = slab_corner<DT>(lds_vox(sb + wb.w)), q111 = slab_corner<DT>(lds_vox(sb + wb.w + 1));
               // back to model order k<dx><dy><dz>: the lerp order (x, y, z) is the gather kernel's
 #define KX(dx, dy, dz)                                                                                   \
   (PERM == 0 ? (dz ? (dy ? (dx ? q111 : q110) : (dx ? q101 : q100)) : (dy ? (dx ? q011 : q010) : (dx ? q001 : q000))) \
@@ -333,7 +511,19 @@ __global__ __launch_bounds__(NT + 64) void smk_k_slab(const RenderParams P, cons
                 if (DT == 0 && P.nelts == 4) ch3 = SMK_TRI(c3) * sc;
               }
               float4 col;
-              if (smk_classify<DT, 1>(P, ch0, ch1, ch2, ch3, col)) {
+              bool hit;
+              if (Q.use_ah) {
+                col = smk_tex2d(P.tf_vg, P.sv, P.sg, ch0, ch1);
+                int h0, h1;
+                float fh;
+                smk_lin_clamp(__fmaf_rn(ch2, (float)P.sv, -0.5f), P.sv, h0, h1, fh);
+                col.w *= smk_lerp(ah[h0], ah[h1], fh) * SMK_INV255;
+                col.w = smk_sat(col.w);
+                hit = col.w != 0.0f;
+              } else {
+                hit = smk_classify<DT, 1>(P, ch0, ch1, ch2, ch3, col);
+              }
+              if (hit) {
                 float4 src;
                 if (SH == 0) {
                   src = smk_shade_sample<0>(P, col, 0.f, 0.f, 0.f, 0.f);
@@ -355,8 +545,12 @@ __global__ __launch_bounds__(NT + 64) void smk_k_slab(const RenderParams P, cons
             bs = (m <= m1) ? base_slice(m) : -0x40000000;
           }
         }
-        __syncthreads();
+        // done with positions [pos, pos+G): their lower slices may be recycled
+        pos += G;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every slot read has returned
+        if (lane == 0) lds_st(&ctl[4 + wave], pos);
       }
+      if (lane == 0) lds_st(&ctl[4 + wave], SLAB_DONE);
     }
   }
   if (live) {
@@ -377,16 +571,16 @@ static void host_ray(const RenderParams &P, int i, int j, double A[3], double B[
   }
 }
 
-template <int DT, int SH, int PERM, int NT>
+template <int DT, int SH, int PERM, int NW>
 static hipError_t launch_slab(const RenderParams &P, const SlabParams &Q, size_t lds, hipStream_t s) {
-  auto k = smk_k_slab<DT, SH, PERM, NT>;
+  auto k = smk_k_slab<DT, SH, PERM, NW>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k, dim3(8 * P.tiles_per_xcd), dim3(NT + 64), lds, s, P, Q);
+  hipLaunchKernelGGL(k, dim3(8 * P.tiles_per_xcd), dim3((NW + 1) * 64), lds, s, P, Q);
   return hipGetLastError();
 }
 
@@ -422,14 +616,14 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
   // u8 voxels are 8 B: the DMA moves 16-B units, so rows must start and end on even voxels
   if (dtype == 0 && ((Q.Du & 1) || (Q.strideV & 1) || (Q.strideS & 1))) { *why = "odd U extent for 8-byte voxels"; return hipErrorNotSupported; }
 
-  // tile shape
+  // tile shape (8x8 sub-tile per consumer wave)
   int tw = 32, th = 16;
   if (opt_tile == 1) { tw = 16; th = 16; }
-  else if (opt_tile == 2) { tw = 32; th = 32; }
+  else if (opt_tile == 2) { tw = 40; th = 24; }
   else if (opt_tile == 3) { tw = 32; th = 8; }
   else if (opt_tile == 4) { tw = 64; th = 8; }
-  else if (opt_tile == 5) { tw = 64; th = 16; }
-  const int nt = tw * th;
+  else if (opt_tile == 5) { tw = 24; th = 16; }
+  const int nw = (tw / 8) * (th / 8);
   Q.tw = tw; Q.th = th;
   P.ntx = (P.W + tw - 1) / tw;
   P.nty = (P.H + th - 1) / th;
@@ -472,28 +666,39 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
   Wu = std::min(Wu, Q.Du);
   Wv = std::min(Wv, Q.Dv);
   if (Wu < 2 || Wv < 2) { *why = "degenerate window"; return hipErrorNotSupported; }
-  if (Wu > 32000 || Wv > 32000) { *why = "window too large"; return hipErrorNotSupported; }
+  if (Wu > 255 || Wv > 255) { *why = "window too large"; return hipErrorNotSupported; }
   const int upv = dtype == 0 ? 2 : 1;
   Q.slot_vox = ((Wu * Wv + 64 * upv - 1) / (64 * upv)) * (64 * upv);
+  Q.chunks = Q.slot_vox / (64 * upv);
+  if (Q.chunks > 63) { *why = "window needs more than 63 DMA chunks"; return hipErrorNotSupported; }
 
   const size_t vb = dtype == 0 ? 8 : 16;
-  int T = opt_T > 0 ? opt_T : 2;
-  for (;; --T) {
-    if (T < 1) { *why = "window does not fit LDS"; return hipErrorNotSupported; }
-    Q.T = T;
-    Q.nslots = 2 * T + 1;
-    size_t lds = (size_t)Q.nslots * Q.slot_vox * vb + (size_t)Q.Ds * sizeof(SlabWin) + 64;
-    if (lds <= 158 * 1024) {
-#define GO(D, S, R, N) \
-  if (dtype == D && shade_kind == S && Q.perm == R && nt == N) return launch_slab<D, S, R, N>(P, Q, lds, s);
-#define GO_NT(D, S, R) GO(D, S, R, 256) GO(D, S, R, 512)
-#define GO_R(D, S) GO_NT(D, S, 0) GO_NT(D, S, 1) GO_NT(D, S, 2)
-      GO_R(0, 0) GO_R(0, 1) GO_R(0, 2) GO_R(1, 0) GO_R(1, 1) GO_R(1, 2)
-#undef GO_R
-#undef GO_NT
-#undef GO
-      *why = "no kernel instance for this tile size";
-      return hipErrorNotSupported;
-    }
+  Q.use_ah = (P.third_axis && P.nelts <= 3 && P.sv <= 2048) ? 1 : 0;
+  Q.gmax = opt_T > 0 ? opt_T : 2;
+  const size_t fixed = (size_t)Q.Ds * sizeof(SlabWin) + (4 + 32) * 4 + 64 + (Q.use_ah ? (size_t)P.sv * 4 : 0);
+  // ring: as many slots as fit two workgroups per CU (or one, for big tiles), at least gmax+3
+  const size_t budget = (nw + 1) * 64 > 512 + 64 ? 158 * 1024 : 78 * 1024;
+  int ns = (int)((budget - fixed) / ((size_t)Q.slot_vox * vb));
+  if (ns > 16) ns = 16;
+  if (ns < 4) {
+    ns = (int)((158 * 1024 - fixed) / ((size_t)Q.slot_vox * vb));
+    if (ns > 8) ns = 8;
   }
+  if (ns < 4) { *why = "window does not fit LDS"; return hipErrorNotSupported; }
+  Q.nslots = ns;
+  if (Q.gmax > ns - 2) Q.gmax = ns - 2;
+  Q.maxfly = std::min(ns - 2, 63 / Q.chunks + 1);
+  if (Q.maxfly < 1) Q.maxfly = 1;
+  if (P.wave_w != 8) Q.maxfly = std::max(1, std::min(P.wave_w, Q.maxfly));  // (experiment knob)
+  const size_t lds = (size_t)ns * Q.slot_vox * vb + fixed;
+#define GO(D, S, R, N) \
+  if (dtype == D && shade_kind == S && Q.perm == R && nw == N) return launch_slab<D, S, R, N>(P, Q, lds, s);
+#define GO_NW(D, S, R) GO(D, S, R, 4) GO(D, S, R, 6) GO(D, S, R, 8) GO(D, S, R, 15)
+#define GO_R(D, S) GO_NW(D, S, 0) GO_NW(D, S, 1) GO_NW(D, S, 2)
+  GO_R(0, 0) GO_R(0, 1) GO_R(0, 2) GO_R(1, 0) GO_R(1, 1) GO_R(1, 2)
+#undef GO_R
+#undef GO_NW
+#undef GO
+  *why = "no kernel instance for this tile size";
+  return hipErrorNotSupported;
 }

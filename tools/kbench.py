@@ -63,6 +63,10 @@ def main():
         print("%-32s kernel=%d  %.3f ms/frame  (event avg %.3f ms)  %.1f GB/s alg  frac %.3f  maxdiff_vs_first %.2e  alpha_mean %.4f"
               % (var, kern, t / a.frames * 1e3, kms, alg / (kms * 1e-3) / 1e9, alg / (kms * 1e-3) / 1e9 / 8000, err, img[:, 3].mean()),
               flush=True)
+        if "lockstep=6" in var or "lockstep=4" in var:
+            t = img[::-1][:1024]
+            t = t[t[:, 3] > 0]
+            print("   loader cycles (mean over %d WGs): issue %.0f  wait %.0f  idle %.0f  total %.0f" % ((len(t),) + tuple(t.mean(0))))
     r.close()
 
 
