@@ -788,11 +788,12 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
   c->slab_why.clear();
   if (c->opt_kernel != 1 && c->tf_mode == 1) {
     const char *why = nullptr;
-    hipError_t e = smk_launch_slab(P, c->dtype, shade_kind_of(c), c->opt_slab_T, c->opt_tile, c->d_vox,
+    const int forced = c->opt_kernel == 2;
+    hipError_t e = smk_launch_slab(P, c->dtype, shade_kind_of(c), c->opt_slab_T, c->opt_tile, forced, c->d_vox,
                                    c->d_vox_x, &why, s);
     if (e == hipErrorNotSupported && why && !strcmp(why, "x-major copy unavailable")) {
       if (make_xmajor_copy(c)) return 1;
-      e = smk_launch_slab(P, c->dtype, shade_kind_of(c), c->opt_slab_T, c->opt_tile, c->d_vox, c->d_vox_x, &why, s);
+      e = smk_launch_slab(P, c->dtype, shade_kind_of(c), c->opt_slab_T, c->opt_tile, forced, c->d_vox, c->d_vox_x, &why, s);
     }
     if (e == hipSuccess) c->last_kernel = 2;
     else if (e == hipErrorNotSupported) {

@@ -122,7 +122,7 @@ struct smk_ctx {
 
   // options / stats
   int opt_kernel = 0, opt_slab_T = 0, opt_tf_raw = 0, opt_tile = 0;
-  int opt_wave_w = 8, opt_blk_w = 2, opt_lockstep = 0;
+  int opt_wave_w = 8, opt_blk_w = 2, opt_lockstep = 1;
   int last_kernel = 0;
   float last_ms = 0;
   double last_alg_bytes = 0;
@@ -132,6 +132,6 @@ struct smk_ctx {
 hipError_t smk_launch_gather(const RenderParams &P, int dtype, int tf_mode, int shade_kind,
                              hipStream_t s);
 // returns hipErrorNotSupported (and *why) when the frame must use the gather kernel
-hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T, int opt_tile,
+hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T, int opt_tile, int forced,
                            const void *vox_native, const void *vox_xmajor, const char **why,
                            hipStream_t s);

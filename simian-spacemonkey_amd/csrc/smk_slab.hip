@@ -585,8 +585,8 @@ static hipError_t launch_slab(const RenderParams &P, const SlabParams &Q, size_t
 }
 
 // plan + launch; returns hipErrorNotSupported when the configuration must use the gather kernel
-hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T, int opt_tile, const void *vox_native,
-                           const void *vox_xmajor, const char **why, hipStream_t s) {
+hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T, int opt_tile, int forced,
+                           const void *vox_native, const void *vox_xmajor, const char **why, hipStream_t s) {
   *why = nullptr;
   if (P.pert_on) { *why = "perturbation"; return hipErrorNotSupported; }
   if (P.N[0] < 2 || P.N[1] < 2 || P.N[2] < 2) { *why = "volume thinner than 2 voxels"; return hipErrorNotSupported; }
@@ -671,6 +671,10 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
   Q.slot_vox = ((Wu * Wv + 64 * upv - 1) / (64 * upv)) * (64 * upv);
   Q.chunks = Q.slot_vox / (64 * upv);
   if (Q.chunks > 63) { *why = "window needs more than 63 DMA chunks"; return hipErrorNotSupported; }
+  // automatic choice (measured, profiles/r01_*): one loader wave issues ~1 KiB of LDS-DMA per
+  // ~250 cycles, so when a tile has to stream more than ~16 B per ray and slice (1024^3 f32 at
+  // one voxel per pixel: 26 B) the gather kernel is still the faster one
+  if (!forced && (double)Q.chunks * 1024.0 / (nw * 64) > 16.0) { *why = "auto: slice windows too heavy per ray for one loader wave"; return hipErrorNotSupported; }
 
   const size_t vb = dtype == 0 ? 8 : 16;
   Q.use_ah = (P.third_axis && P.nelts <= 3 && P.sv <= 2048) ? 1 : 0;

@@ -59,6 +59,16 @@ def tf3d_dense(n=16, seed=5):
     return t
 
 
+# principal axis / marching direction coverage for the slice-ring kernel: views roughly along
+# +-z, +-y, +-x (the last needs the x-major copy), each a little off-axis
+POSES = {
+    "z+": ((0.3, 1, 0.2), 12), "z-": ((0.1, 1, 0.05), 171),
+    "y+": ((1, 0.15, 0.1), 80), "y-": ((1, -0.1, 0.2), -97),
+    "x+": ((0.1, 1, 0.2), 82), "x-": ((0.15, 1, -0.1), -95),
+    "diag": ((1, 1, 1), 50),
+}
+
+
 def make_scene(kind, n=32, size=48, steps=48, pose="rot", f32=False, shade=0, third=False,
                pert=False, dims=None):
     """kind: 'cfg1' (u8 scalar, 1-D TLUT), 'cfg2' (VGH, 2-D TF), 'cfg3' (VGH, LevWidget TF),
@@ -97,6 +107,8 @@ def make_scene(kind, n=32, size=48, steps=48, pose="rot", f32=False, shade=0, th
         sc.xform = O.rotation((0, 1, 0), 160)
     elif pose == "side":
         sc.xform = O.rotation((.2, 1, .1), 75)
+    elif pose in POSES:
+        sc.xform = O.rotation(*POSES[pose])
     sc.shade_mode = shade
     if pert:
         sc.noise = O.noise_tex(32)
