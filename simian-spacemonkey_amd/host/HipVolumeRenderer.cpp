@@ -1,0 +1,172 @@
+// HipVolumeRenderer.cpp -- see the header.  Every GL call of the reference path is replaced by
+// one smk_* call; everything else (who owns what, when tables are re-sent, error style) follows
+// the reference files cited inline.
+#include "HipVolumeRenderer.h"
+
+#include <cstdio>
+#include <iostream>
+
+static void build_modelview(double mv[16]);  // LookAt * T(trans) * R(xform) * T(-size/2)
+
+HipVolumeRenderer::HipVolumeRenderer(MetaVolume *vm, int, int device) : ctx(nullptr), m_vol(vm), tlut(nullptr), failed(0) {
+  int err = 0;
+  ctx = smk_create(device, &err);
+  if (!ctx) {
+    std::cerr << "ERROR: HipVolumeRenderer: " << smk_last_error(nullptr) << std::endl;
+    failed = 1;
+  }
+}
+
+HipVolumeRenderer::~HipVolumeRenderer() {
+  if (tlut) delete tlut;  // VolumeRenderer.h:89
+  smk_destroy(ctx);
+}
+
+int HipVolumeRenderer::upload(Volume *v, int n) {
+  if (!ctx) return 1;
+  std::vector<smk_volume_desc> d(n);
+  for (int i = 0; i < n; ++i) {
+    d[i].xiSize = v[i].xiSize; d[i].yiSize = v[i].yiSize; d[i].ziSize = v[i].ziSize;
+    d[i].xfSize = v[i].xfSize; d[i].yfSize = v[i].yfSize; d[i].zfSize = v[i].zfSize;
+    d[i].xiPos = v[i].xiPos; d[i].yiPos = v[i].yiPos; d[i].ziPos = v[i].ziPos;
+    d[i].xfPos = v[i].xfPos; d[i].yfPos = v[i].yfPos; d[i].zfPos = v[i].zfPos;
+    d[i].data = v[i].currentData;
+    d[i].grad = v[i].currentGrad;
+  }
+  if (smk_upload_volume(ctx, d.data(), n, m_vol->nelts, SMK_U8, (smk_datamode)gluvv.dmode)) {
+    std::cerr << "ERROR: HipVolumeRenderer::createVolume: " << smk_last_error(ctx) << std::endl;
+    failed = 1;
+    return 1;
+  }
+  return 0;
+}
+
+int HipVolumeRenderer::createVolume(int type, Volume *v) {
+  if (type != VolRen3DExt) {  // VolumeRenderer.cpp:103-112: the other modes "not implemented"
+    std::cerr << "texture mapping method is not implemented" << std::endl;
+    return 1;
+  }
+  return upload(v, 1);
+}
+
+int HipVolumeRenderer::createVolume(int type, Volume *v, int nVols) {
+  if (type != VolRen3DExt) {
+    std::cerr << "texture mapping method is not implemented" << std::endl;
+    return 1;
+  }
+  return upload(v, nVols);
+}
+
+int HipVolumeRenderer::createTLUT() {
+  tlut = new TLUT;
+  return 1;
+}
+
+void HipVolumeRenderer::loadTransferTableRGBA() {
+  if (!ctx || !tlut) return;
+  if (smk_set_tlut1d(ctx, tlut->GetRGBA(0), tlut->GetSize())) {
+    std::cerr << "ERROR: HipVolumeRenderer::loadTransferTableRGBA: " << smk_last_error(ctx) << std::endl;
+    failed = 1;
+  }
+}
+
+void HipVolumeRenderer::renderVolume(float sampleRate, double mv[16]) {
+  if (!ok()) return;
+  const int W = (int)gluvv.win.width, H = (int)gluvv.win.height;
+  fb.assign((size_t)W * H * 4, 0.0f);
+  int rc = smk_set_camera(ctx, mv, gluvv.env.frustum, gluvv.env.clip, W, H);
+  rc |= smk_set_sampling(ctx, sampleRate, 0, gluvv.volren.gamma, gluvv.volren.scaleAlphas);
+  if (!rc) rc = smk_render(ctx, fb.data(), nullptr);
+  if (rc) {
+    std::cerr << "ERROR: HipVolumeRenderer::renderVolume: " << smk_last_error(ctx) << std::endl;
+    failed = 1;
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+
+void HipVolumeRenderable::init() {
+  if (!gluvv.mv) {  // VolumeRenderable.cpp:62-65
+    std::cerr << "ERROR: HipVolumeRenderable::init(), no MetaVolume defined" << std::endl;
+    return;
+  }
+  volren = new HipVolumeRenderer(gluvv.mv, 0, device);
+  int bad;
+  if (gluvv.mv->numSubVols == 1) bad = volren->createVolume(VolRen3DExt, gluvv.mv->volumes);
+  else bad = volren->createVolume(VolRen3DExt, gluvv.mv->volumes, gluvv.mv->numSubVols);
+  if (bad || !volren->ok()) return;  // go stays 0: draw() is a no-op (NV20VolRen3D.cpp:44-65)
+  if (gluvv.dmode == GDM_V1 && !gluvv.volren.deptex) {
+    // scalar path: 1-D TLUT owned by the renderer, published in gluvv.volren.tlut
+    // (VolumeRenderable.cpp:72-78; the preset colormaps are the caller's to choose)
+    volren->createTLUT();
+    gluvv.volren.tlut = volren->getColorMap();
+    volren->loadTransferTableRGBA();
+  } else {
+    gluvv.volren.loadTLUT = 1;  // first draw() sends deptex/deptex2 (NV20VolRen3D.cpp:91-122)
+  }
+  go = 1;
+}
+
+void HipVolumeRenderable::draw() {
+  if (!go || !volren) return;
+  if (gluvv.reblend) return;  // R8kVolRen3D.cpp:177
+  if (gluvv.picking) return;  // :179
+  double mv[16];
+  build_modelview(mv);
+  smk_ctx *c = volren->context();
+  if (gluvv.volren.tlut && gluvv.dmode == GDM_V1 && !gluvv.volren.deptex) {
+    // VolumeRenderable::draw (:50-54): opacity-correct the TLUT for the sample rate, re-send
+    if (volren->getColorMap()->scaleAlpha(gluvv.volren.sampleRate) || gluvv.volren.loadTLUT) {
+      gluvv.volren.loadTLUT = 0;
+      volren->loadTransferTableRGBA();
+    }
+  } else if (gluvv.volren.loadTLUT) {
+    // TFWidgetRen raised loadTLUT after rasterising into deptex (TFWidgetRen1.cpp:232-242)
+    if (smk_set_tf2d(c, gluvv.volren.deptex, gluvv.volren.deptex2, gluvv.tf.ptexsz[0], gluvv.tf.ptexsz[1]))
+      std::cerr << "ERROR: HipVolumeRenderable::draw: " << smk_last_error(c) << std::endl;
+    gluvv.volren.loadTLUT = 0;
+  }
+  smk_shade sm = SMK_SHADE_NONE;
+  if (gluvv.shade == gluvvShadeDiff) sm = SMK_SHADE_R8K_DIFF;
+  if (gluvv.shade == gluvvShadeDSpec) sm = SMK_SHADE_R8K_DSPEC;
+  smk_set_shading(c, sm, gluvv.light.pos, gluvv.env.eye, gluvv.env.at, gluvv.rinfo.xform, gluvv.light.intens, gluvv.light.amb);
+  volren->renderVolume(gluvv.volren.sampleRate, mv);
+  if (!volren->ok()) go = 0;
+}
+
+// gluLookAt(eye,at,up) * T(trans) * R(xform) * T(-size/2)   (gluvv.cpp:531-540, VolumeRenderable.cpp:40-46)
+static void mul(double o[16], const double a[16], const double b[16]) {
+  double t[16];
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      double s = 0;
+      for (int k = 0; k < 4; ++k) s += a[k * 4 + r] * b[c * 4 + k];
+      t[c * 4 + r] = s;
+    }
+  memcpy(o, t, sizeof t);
+}
+static void translate(double m[16], double x, double y, double z) {
+  memset(m, 0, 16 * sizeof(double));
+  m[0] = m[5] = m[10] = m[15] = 1;
+  m[12] = x; m[13] = y; m[14] = z;
+}
+static void build_modelview(double mv[16]) {
+  const float *e = gluvv.env.eye, *a = gluvv.env.at, *u = gluvv.env.up;
+  double f[3] = {a[0] - e[0], a[1] - e[1], a[2] - e[2]};
+  double fl = sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+  for (double &x : f) x /= fl;
+  double s[3] = {f[1] * u[2] - f[2] * u[1], f[2] * u[0] - f[0] * u[2], f[0] * u[1] - f[1] * u[0]};
+  double sl = sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]);
+  for (double &x : s) x /= sl;
+  double uu[3] = {s[1] * f[2] - s[2] * f[1], s[2] * f[0] - s[0] * f[2], s[0] * f[1] - s[1] * f[0]};
+  double la[16] = {s[0], uu[0], -f[0], 0, s[1], uu[1], -f[1], 0, s[2], uu[2], -f[2], 0, 0, 0, 0, 1};
+  double t[16], r[16];
+  translate(t, -e[0], -e[1], -e[2]);
+  mul(mv, la, t);
+  translate(t, gluvv.rinfo.trans[0], gluvv.rinfo.trans[1], gluvv.rinfo.trans[2]);
+  mul(mv, mv, t);
+  for (int i = 0; i < 16; ++i) r[i] = gluvv.rinfo.xform[i];
+  mul(mv, mv, r);
+  translate(t, -gluvv.mv->xfSize / 2, -gluvv.mv->yfSize / 2, -gluvv.mv->zfSize / 2);
+  mul(mv, mv, t);
+}

@@ -1,0 +1,82 @@
+// Drives the host-side mirror the way Simian's main() drives a renderer (gluvv.cpp:141-199,
+// 518-525, 593-597): fill `gluvv`, new the primitive, link it, init() once, draw() per frame.
+// usage: adapter_main <vol.u8 nx ny nz nelts> <grad.u8|-> <deptex.rgba|-> <W> <H> <rate> <shade 0|3> <xform16...> <out.f32>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "HipVolumeRenderer.h"
+
+gluvvGlobal gluvv;
+
+static std::vector<unsigned char> slurp(const char *p) {
+  std::vector<unsigned char> v;
+  FILE *f = fopen(p, "rb");
+  if (!f) return v;
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  v.resize(n);
+  if (fread(v.data(), 1, n, f) != (size_t)n) v.clear();
+  fclose(f);
+  return v;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 12 + 16) {
+    fprintf(stderr, "bad usage\n");
+    return 2;
+  }
+  int a = 1;
+  auto vol = slurp(argv[a++]);
+  int nx = atoi(argv[a++]), ny = atoi(argv[a++]), nz = atoi(argv[a++]), ne = atoi(argv[a++]);
+  auto grad = slurp(argv[a++]);
+  auto dep = slurp(argv[a++]);
+  gluvv.win.width = atoi(argv[a++]);
+  gluvv.win.height = atoi(argv[a++]);
+  gluvv.volren.sampleRate = (float)atof(argv[a++]);
+  gluvv.shade = (gluvvShade)atoi(argv[a++]);
+  for (int i = 0; i < 16; ++i) gluvv.rinfo.xform[i] = (float)atof(argv[a++]);
+  const char *out = argv[a++];
+  if (vol.size() != (size_t)nx * ny * nz * ne) {
+    fprintf(stderr, "volume size mismatch\n");
+    return 2;
+  }
+  // MetaVolume as the loader leaves it: one brick, largest dimension normalised to 1
+  MetaVolume mv;
+  Volume v;
+  int mx = nx > ny ? (nx > nz ? nx : nz) : (ny > nz ? ny : nz);
+  mv.xiSize = v.xiSize = nx; mv.yiSize = v.yiSize = ny; mv.ziSize = v.ziSize = nz;
+  mv.xfSize = v.xfSize = nx / (float)mx; mv.yfSize = v.yfSize = ny / (float)mx; mv.zfSize = v.zfSize = nz / (float)mx;
+  v.currentData = vol.data();
+  v.currentGrad = grad.empty() ? nullptr : grad.data();
+  mv.volumes = &v;
+  mv.numSubVols = 1;
+  mv.nelts = ne;
+  gluvv.mv = &mv;
+  gluvv.dmode = ne == 1 ? GDM_V1 : GDM_VGH;
+  const float fr = 0.5f / 7;
+  gluvv.env.frustum[0] = -fr; gluvv.env.frustum[1] = fr; gluvv.env.frustum[2] = -fr; gluvv.env.frustum[3] = fr;
+  if (!dep.empty()) gluvv.volren.deptex = dep.data();
+
+  gluvvPrimitive renderables;                 // "Dummy Node" list head (gluvv.cpp:252)
+  HipVolumeRenderable *r = new HipVolumeRenderable(0);
+  renderables.setNext(r);
+  for (gluvvPrimitive *p = renderables.getNext(); p; p = p->getNext()) p->init();   // initRenderables
+  if (!r->running()) {
+    fprintf(stderr, "renderer did not start (no HIP device?)\n");
+    return 3;
+  }
+  if (ne == 1) {  // VolumeRenderable::init's colour map: here a plain alpha ramp 0 -> .1
+    TLUT *t = gluvv.volren.tlut;
+    for (int n = 0; n < t->GetSize(); ++n) t->GetRGBA(n)[3] = 0.1f * n / (t->GetSize() - 1);
+    gluvv.volren.loadTLUT = 1;
+  }
+  for (gluvvPrimitive *p = renderables.getNext(); p; p = p->getNext()) p->draw();   // display()
+  if (!r->running()) return 4;
+  FILE *f = fopen(out, "wb");
+  fwrite(r->framebuffer(), 4, (size_t)gluvv.win.width * gluvv.win.height * 4, f);
+  fclose(f);
+  delete r;
+  return 0;
+}
