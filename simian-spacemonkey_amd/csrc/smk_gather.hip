@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
   const int Dx = P.D[0], Dy = P.D[1];
 
   for (int m = mlo; m <= mhi; ++m) {
+    if (!__any(m <= m1)) break;  // every ray of the wave is past its last plane (or saturated)
     if (m < m0 || m > m1) continue;
     float p0 = __fmaf_rn((float)m, B[0], A[0]);
     float p1 = __fmaf_rn((float)m, B[1], A[1]);
@@ -152,6 +153,9 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
     C1 = __fmaf_rn(w, src.y, C1);
     C2 = __fmaf_rn(w, src.z, C2);
     C3 = __fmaf_rn(w, src.w, C3);
+    // exact early termination: once A == 1.0f every later weight (1-A) is exactly 0, so no
+    // later sample can change C or A (nor the first-hit depth)
+    if (C3 == 1.0f) m1 = m;
   }
   if (!live) return;
   size_t o = (size_t)j * P.W + i;

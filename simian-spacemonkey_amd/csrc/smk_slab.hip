@@ -429,19 +429,12 @@ __global__ __launch_bounds__((NW + 1) * 64) void smk_k_slab(const RenderParams P
       }
     } else {
       // ================================ consumer waves ==========================================
+      int have = 0;  // cached copy of `landed` (monotonic): re-polled only when it is too small
       while (pos < npos) {
-        // fast-forward to the first position any lane still has a sample in
-        int pn = (m <= m1) ? pos_of(bs) : SLAB_DONE;
-        for (int o = 32; o > 0; o >>= 1) pn = min(pn, __shfl_xor(pn, o));
-        pn = __builtin_amdgcn_readfirstlane(pn);
-        if (pn >= SLAB_DONE) break;
-        if (pn > pos) {
-          pos = pn;
-          if (lane == 0) lds_st(&ctl[4 + wave], pos);
-        }
+        if (!__any(m <= m1)) break;  // every ray of this wave is finished
         // wait until the slices of position pos (load indices pos, pos+1) have landed; take up
         // to gmax positions if more are already resident
-        int have = lds_ld(&ctl[2]);
+        if (have < pos + 1 + Q.gmax) have = lds_ld(&ctl[2]);
         for (int spins = 0; have < pos + 2; ++spins) {
           if (spins > (1 << 22) || lds_ld(&ctl[3])) {  // bounded: never hang the GPU on a protocol bug
             lds_st(&ctl[3], 1);
@@ -539,6 +532,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void smk_k_slab(const RenderParams P
                 C1 = __fmaf_rn(w, src.y, C1);
                 C2 = __fmaf_rn(w, src.z, C2);
                 C3 = __fmaf_rn(w, src.w, C3);
+                // exact early termination: once A == 1.0f every later weight (1-A) is exactly 0,
+                // so no later sample can change C or A (nor the first-hit depth)
+                if (C3 == 1.0f) m1 = m;
               }
             }
             ++m;
