@@ -18,11 +18,14 @@
 #define SMK_INV255 (1.0f / 255.0f)
 
 __device__ __forceinline__ float smk_lerp(float a, float b, float f) { return __fmaf_rn(f, b - a, a); }
-__device__ __forceinline__ float smk_sat(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+// clamp as ONE v_med3_f32 (fminf/fmaxf make hipcc add a canonicalising v_max first); for the
+// finite values that occur here med3(x,lo,hi) == min(max(x,lo),hi) exactly
+__device__ __forceinline__ float smk_clampf(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ float smk_sat(float x) { return smk_clampf(x, 0.0f, 1.0f); }
 
 // GL_LINEAR + clamp-to-edge along one axis, x in texel units
 __device__ __forceinline__ void smk_lin_clamp(float x, int n, int &i0, int &i1, float &f) {
-  float xc = fminf(fmaxf(x, 0.0f), (float)(n - 1));
+  float xc = smk_clampf(x, 0.0f, (float)(n - 1));
   int i = (int)xc;
   int imax = n >= 2 ? n - 2 : 0;
   i = min(i, imax);
@@ -192,7 +195,7 @@ __device__ __forceinline__ float4 smk_shade_sample(const RenderParams &P, float4
     w2 *= il;
     float dl = fabsf(__fmaf_rn(P.L[0], w0, __fmaf_rn(P.L[1], w1, P.L[2] * w2)));
     float dh = fabsf(__fmaf_rn(P.Hv[0], w0, __fmaf_rn(P.Hv[1], w1, P.Hv[2] * w2)));
-    float kd = smk_sat(fmaxf(smk_sat(dl), 0.2f)) * P.intens;
+    float kd = smk_clampf(dl, 0.2f, 1.0f) * P.intens;  // == sat(max(sat(dl), .2))
     float ks = P.use_spec ? smk_sat(smk_pow30(smk_sat(dh))) * P.intens : 0.0f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {

@@ -154,28 +154,33 @@ __device__ __forceinline__ void raw_lds_st_b32(void *p, int v) {
   asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
 }
 
-// NW = consumer waves (64 rays each); the block has (NW+1)*64 threads, the last wave is the loader
-template <int DT, int SH, int PERM, int NW>
-__global__ __launch_bounds__((NW + 1) * 64) void smk_k_slab(const RenderParams P, const SlabParams Q) {
+// NW = consumer waves (64 rays each), NL = loader waves; the block has (NW+NL)*64 threads, the
+// last NL waves are loaders: loader l streams DMA chunks l, l+NL, ... of every slice
+// second launch-bound = waves per SIMD wanted: workgroups of 5/9/10 waves only double up on a CU
+// (2 x 9 waves = 5 on one SIMD) if the kernel stays within 96 VGPRs
+template <int DT, int SH, int PERM, int NW, int NL>
+__global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9 || (NW + NL) == 5 || (NW + NL) == 10) ? 5 : 4) void smk_k_slab(const RenderParams P, const SlabParams Q) {
   typedef typename VoxT<DT>::type Vox;
   constexpr int UPV = DT == 0 ? 2 : 1;  // voxels per 16-byte DMA unit
-  constexpr int NTH = (NW + 1) * 64;
+  constexpr int NTH = (NW + NL) * 64;
   extern __shared__ __align__(16) unsigned char smem[];
   // LDS carve: ring [nslots][slot_vox] voxels | window table [Ds] | control words | alpha_H
   Vox *ring = reinterpret_cast<Vox *>(smem);
   const int slot_vox = Q.slot_vox;
   SlabWin *wtab = reinterpret_cast<SlabWin *>(smem + (size_t)Q.nslots * slot_vox * sizeof(Vox));
-  int *ctl = reinterpret_cast<int *>(wtab + Q.Ds);  // [0] smin [1] smax [2] landed [4..4+NW) progress
+  // control words: [0] smin [1] smax [3] protocol time-out [4..4+NL) landed per loader [8..8+NW) progress
+  int *ctl = reinterpret_cast<int *>(wtab + Q.Ds);
   // third-axis alpha as a 1-D table: with <= 3 channels the (H,4th) lookup has t = 0, i.e. row
   // 0 of deptex2 with a zero t-weight, so lerp(row0[s0], row0[s1], fs) is the SAME float
-  float *ah = reinterpret_cast<float *>(ctl + 4 + 32);
+  float *ah = reinterpret_cast<float *>(ctl + 8 + 32);
 
   int tx, ty;
   if (!smk_tile_of_block(P, blockIdx.x, tx, ty)) return;  // whole workgroup leaves together
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const bool is_loader = wave == NW;
+  const bool is_loader = wave >= NW;
+  const int lid = wave - NW;  // loader index
   // consumer wave = 8x8 pixel sub-tile; waves laid out row-major over the tile
   const int wpr = Q.tw >> 3;
   const int i = tx * Q.tw + (wave % wpr) * 8 + (lane & 7);
@@ -217,7 +222,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void smk_k_slab(const RenderParams P
   // base slice index of plane q on this ray (a sample reads slices i0 and i0+1)
   auto base_slice = [&](int q) -> int {
     float s = __fmaf_rn((float)q, B[AS], A[AS]);
-    float sc = fminf(fmaxf(s, 0.0f), (float)(NS - 1));
+    float sc = smk_clampf(s, 0.0f, (float)(NS - 1));
     return min((int)sc, NS - 2);
   };
 
@@ -225,10 +230,10 @@ __global__ __launch_bounds__((NW + 1) * 64) void smk_k_slab(const RenderParams P
   if (tid == 0) {
     ctl[0] = 0x7fffffff;
     ctl[1] = -0x7fffffff;
-    ctl[2] = 0;
     ctl[3] = 0;  // protocol time-out flag (bounded spins)
+    ctl[4] = ctl[5] = ctl[6] = ctl[7] = 0;
   }
-  if (tid < 32) ctl[4 + tid] = SLAB_DONE;
+  if (tid < 32) ctl[8 + tid] = SLAB_DONE;
   __syncthreads();
   {
     int lo = 0x7fffffff, hi = -0x7fffffff;
@@ -302,6 +307,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void smk_k_slab(const RenderParams P
         u0 &= ~1;
         u1 |= 1;  // the stored U extent is even (host check)
       }
+
       int w = max(u1 - u0 + 1, 0), h = max(v1 - v0 + 1, 0);
       if (w * h > slot_vox) h = w > 0 ? slot_vox / w : 0;  // never overrun a slot (host sizes it)
       SlabWin ww;
@@ -321,7 +327,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void smk_k_slab(const RenderParams P
     int p0 = (m <= m1) ? pos_of(bs) : SLAB_DONE;
     for (int o = 32; o > 0; o >>= 1) p0 = min(p0, __shfl_xor(p0, o));
     pos = p0;
-    if (lane == 0) ctl[4 + wave] = pos;
+    if (lane == 0) ctl[8 + wave] = pos;
   }
   __syncthreads();  // table, alpha_H, control words visible; LAST workgroup barrier
   float C0 = 0.f, C1 = 0.f, C2 = 0.f, C3 = 0.f;
@@ -338,13 +344,14 @@ __global__ __launch_bounds__((NW + 1) * 64) void smk_k_slab(const RenderParams P
       __builtin_amdgcn_s_setprio(3);  // the stream must never wait for issue slots behind pollers
       const char *gv = reinterpret_cast<const char *>(Q.vox);
       const int chunks = Q.chunks;
+      const int mych = (chunks - lid + NL - 1) / NL;  // DMA instructions THIS loader issues per slice
       const unsigned strideVb = (unsigned)(Q.strideV * (long long)sizeof(Vox));  // bytes, < 2^32
       int q = 0, inflight = 0, landed = 0, idle = 0, minp = 0;
       long long t_issue = 0, t_wait = 0, t_idle = 0, t_all = __builtin_amdgcn_s_memtime(), t0_ = 0;
       const bool prof = (P.lockstep & 4) != 0;  // (diagnostic build switch: loader cycle shares)
       auto poll_progress = [&]() -> int {
         int v = SLAB_DONE;
-        if (lane < NW) v = raw_lds_b32(&ctl[4 + lane]);
+        if (lane < NW) v = raw_lds_b32(&ctl[8 + lane]);
         for (int o = 16; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
         return __builtin_amdgcn_readfirstlane(v);
       };
@@ -375,20 +382,23 @@ __global__ __launch_bounds__((NW + 1) * 64) void smk_k_slab(const RenderParams P
             // (diagnostic bit 8: every slice re-reads slice 0 -> L2-hot stream, isolates issue cost)
             const size_t sl_src = (P.lockstep & 8) ? 0 : (size_t)sl;
             const char *base = gv + (sl_src * Q.strideS + (size_t)w.v0 * Q.strideV + (size_t)w.u0) * sizeof(Vox);
-            // lane's unit: idx = 64*c + lane = row*wu + col, advanced incrementally per chunk
-            const int q64 = 64 / wu, r64 = 64 - q64 * wu;
-            const int row0 = lane / wu;
-            int col = lane - row0 * wu;
+            // this loader's chunks c = lid, lid+NL, ...; lane's unit idx = 64*c + lane =
+            // row*wu + col, advanced incrementally by 64*NL units per step
+            const int adv = 64 * NL;
+            const int qa = adv / wu, ra = adv - qa * wu;
+            const int idx0 = lid * 64 + lane;
+            const int row0 = idx0 / wu;
+            int col = idx0 - row0 * wu;
             unsigned off = (unsigned)row0 * strideVb + (unsigned)col * 16u;
-            const unsigned step = (unsigned)q64 * strideVb + (unsigned)r64 * 16u;
+            const unsigned step = (unsigned)qa * strideVb + (unsigned)ra * 16u;
             const unsigned wrap = strideVb - (unsigned)wu * 16u;
-            int left = n - lane;  // > 0 while this lane's unit is inside the window
-            for (int c = 0; c < chunks; ++c) {
+            int left = n - idx0;  // > 0 while this lane's unit is inside the window
+            for (int c = lid; c < chunks; c += NL) {
               const unsigned o = left > 0 ? off : 0u;
               // LDS address = wave-uniform base + lane*16: the slot image is flat in unit order
               __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + o), (lds_ptr_t)(dst + c * 64 * UPV), 16, 0, 0);
-              left -= 64;
-              col += r64;
+              left -= adv;
+              col += ra;
               off += step;
               if (col >= wu) {
                 col -= wu;
@@ -397,7 +407,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void smk_k_slab(const RenderParams P
             }
           } else {
             // slice outside the stored box (never read): keep the instruction count uniform
-            for (int c = 0; c < chunks; ++c)
+            for (int c = lid; c < chunks; c += NL)
               __builtin_amdgcn_global_load_lds((glb_ptr_t)gv, (lds_ptr_t)(ring + (q % nslots) * slot_vox + c * 64 * UPV), 16, 0, 0);
           }
           ++q;
@@ -408,11 +418,11 @@ __global__ __launch_bounds__((NW + 1) * 64) void smk_k_slab(const RenderParams P
         if (inflight > 0) {
           // retire the oldest slice in flight: all but the (inflight-1) younger slices' DMAs done
           if (prof) t0_ = __builtin_amdgcn_s_memtime();
-          wait_vmcnt(chunks * (inflight - 1));
+          wait_vmcnt(mych * (inflight - 1));
           if (prof) t_wait += __builtin_amdgcn_s_memtime() - t0_;
           --inflight;
           ++landed;
-          raw_lds_st_b32(&ctl[2], landed);
+          raw_lds_st_b32(&ctl[4 + lid], landed);
         } else {
           if (prof) t_idle += 200;
           if (++idle > (1 << 22) || raw_lds_b32(&ctl[3])) {  // bounded spin (see consumers)
@@ -429,12 +439,19 @@ __global__ __launch_bounds__((NW + 1) * 64) void smk_k_slab(const RenderParams P
       }
     } else {
       // ================================ consumer waves ==========================================
+      // slices landed = the slowest loader's count
+      auto landed_all = [&]() -> int {
+        int v = lds_ld(&ctl[4]);
+#pragma unroll
+        for (int l = 1; l < NL; ++l) v = min(v, lds_ld(&ctl[4 + l]));
+        return v;
+      };
       int have = 0;  // cached copy of `landed` (monotonic): re-polled only when it is too small
       while (pos < npos) {
         if (!__any(m <= m1)) break;  // every ray of this wave is finished
         // wait until the slices of position pos (load indices pos, pos+1) have landed; take up
         // to gmax positions if more are already resident
-        if (have < pos + 1 + Q.gmax) have = lds_ld(&ctl[2]);
+        if (have < pos + 1 + Q.gmax) have = landed_all();
         for (int spins = 0; have < pos + 2; ++spins) {
           if (spins > (1 << 22) || lds_ld(&ctl[3])) {  // bounded: never hang the GPU on a protocol bug
             lds_st(&ctl[3], 1);
@@ -443,14 +460,25 @@ __global__ __launch_bounds__((NW + 1) * 64) void smk_k_slab(const RenderParams P
             break;
           }
           __builtin_amdgcn_s_sleep(4);
-          have = lds_ld(&ctl[2]);
+          have = landed_all();
         }
         if (pos >= npos) break;
         have = __builtin_amdgcn_readfirstlane(have);
         asm volatile("" ::: "memory");  // slot reads stay behind the poll
         const int G = min(min(Q.gmax, have - pos - 1), npos - pos);
         const int b0 = dir > 0 ? smin + pos : smax - pos - G + 1, b1 = b0 + G - 1;
+        // windows of slices b0 .. b1+1 (at most 4): wave-uniform, fetched once per step into SGPRs
+        // so a sample's address does not start with a dependent LDS round trip
+        uint2 we[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const uint2 raw = *reinterpret_cast<const uint2 *>(&wtab[min(b0 + k, smax + 1) - Q.Os]);
+          we[k].x = __builtin_amdgcn_readfirstlane(raw.x);
+          we[k].y = __builtin_amdgcn_readfirstlane(raw.y);
+        }
         // ---- all samples of this ray whose base slice lies in [b0, b1]
+        // (a two-phase variant -- walk to the next alpha>0 sample, then shade all lanes together --
+        //  was measured 1.45x SLOWER on the LevWidget scene: hits are not sparse enough there)
         while (true) {
           const bool act = bs >= b0 && bs <= b1 && !(P.lockstep & 2);  // (debug bit 2: stream only)
           if (!__any(act)) break;
@@ -473,7 +501,12 @@ __global__ __launch_bounds__((NW + 1) * 64) void smk_k_slab(const RenderParams P
               smk_lin_clamp(p[2], P.N[2], z0, z1, fz);
               const int iu = (AU == 0 ? x0 : y0) - Q.Ou, iv = (AV == 1 ? y0 : z0) - Q.Ov;
               const int is = (AS == 2 ? z0 : (AS == 1 ? y0 : x0));
-              const SlabWin wa = wtab[is - Q.Os], wb = wtab[is + 1 - Q.Os];
+              const int kk = is - b0;  // 0 .. G-1 (G <= 3)
+              const uint2 ea = kk == 0 ? we[0] : (kk == 1 ? we[1] : we[2]);
+              const uint2 eb = kk == 0 ? we[1] : (kk == 1 ? we[2] : we[3]);
+              SlabWin wa, wb;
+              memcpy(&wa, &ea, sizeof wa);
+              memcpy(&wb, &eb, sizeof wb);
               // clamp into the resident windows (never alters a result: windows cover the bundle)
               const int ca = min(max(iu - wa.u0, 0), wa.w - 2), ra = min(max(iv - wa.v0, 0), wa.h - 2);
               const int cb = min(max(iu - wb.u0, 0), wb.w - 2), rb = min(max(iv - wb.v0, 0), wb.h - 2);
@@ -544,9 +577,9 @@ __global__ __launch_bounds__((NW + 1) * 64) void smk_k_slab(const RenderParams P
         // done with positions [pos, pos+G): their lower slices may be recycled
         pos += G;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every slot read has returned
-        if (lane == 0) lds_st(&ctl[4 + wave], pos);
+        if (lane == 0) lds_st(&ctl[8 + wave], pos);
       }
-      if (lane == 0) lds_st(&ctl[4 + wave], SLAB_DONE);
+      if (lane == 0) lds_st(&ctl[8 + wave], SLAB_DONE);
     }
   }
   if (live) {
@@ -567,16 +600,16 @@ static void host_ray(const RenderParams &P, int i, int j, double A[3], double B[
   }
 }
 
-template <int DT, int SH, int PERM, int NW>
+template <int DT, int SH, int PERM, int NW, int NL>
 static hipError_t launch_slab(const RenderParams &P, const SlabParams &Q, size_t lds, hipStream_t s) {
-  auto k = smk_k_slab<DT, SH, PERM, NW>;
+  auto k = smk_k_slab<DT, SH, PERM, NW, NL>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k, dim3(8 * P.tiles_per_xcd), dim3((NW + 1) * 64), lds, s, P, Q);
+  hipLaunchKernelGGL(k, dim3(8 * P.tiles_per_xcd), dim3((NW + NL) * 64), lds, s, P, Q);
   return hipGetLastError();
 }
 
@@ -612,93 +645,106 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
   // u8 voxels are 8 B: the DMA moves 16-B units, so rows must start and end on even voxels
   if (dtype == 0 && ((Q.Du & 1) || (Q.strideV & 1) || (Q.strideS & 1))) { *why = "odd U extent for 8-byte voxels"; return hipErrorNotSupported; }
 
-  // tile shape (8x8 sub-tile per consumer wave)
-  int tw = 32, th = 16;
-  if (opt_tile == 1) { tw = 16; th = 16; }
-  else if (opt_tile == 2) { tw = 40; th = 24; }
-  else if (opt_tile == 3) { tw = 32; th = 8; }
-  else if (opt_tile == 4) { tw = 64; th = 8; }
-  else if (opt_tile == 5) { tw = 24; th = 16; }
-  const int nw = (tw / 8) * (th / 8);
-  Q.tw = tw; Q.th = th;
-  P.ntx = (P.W + tw - 1) / tw;
-  P.nty = (P.H + th - 1) / th;
-  P.tiles_per_xcd = (P.ntx * P.nty + 7) / 8;
+  // workgroup shape: consumer waves are 8x8 pixel sub-tiles; NL loader waves.
+  //   light windows (<= ~16 B per ray and slice): 32x16 tile, 8+1 waves, two workgroups per CU
+  //   heavy windows (1024^3 f32 at a voxel per pixel: 26 B): 32x24 tile, 12+4 waves, one per CU
+  // (one loader wave issues ~1 KiB of LDS-DMA per ~250 cycles incl. its address arithmetic:
+  //  profiles/r01_*; so the stream needs several loader waves per CU to approach HBM speed)
+  struct Cfg { int tw, th, nl; };
+  Cfg cfgs[2] = {{32, 16, 1}, {32, 24, 4}};
+  int ncfg = 2;
+  if (opt_tile == 1) { cfgs[0] = {16, 16, 1}; ncfg = 1; }
+  else if (opt_tile == 2) { cfgs[0] = {32, 24, 4}; ncfg = 1; }
+  else if (opt_tile == 3) { cfgs[0] = {24, 16, 2}; ncfg = 1; }
+  else if (opt_tile == 4) { cfgs[0] = {64, 8, 1}; ncfg = 1; }
+  else if (opt_tile == 5) { cfgs[0] = {32, 16, 2}; ncfg = 1; }
+  else if (opt_tile == 6) { cfgs[0] = {32, 16, 1}; ncfg = 1; }
+  else if (opt_tile == 8) { cfgs[0] = {32, 16, 4}; ncfg = 1; }
+  const int upv = dtype == 0 ? 2 : 1;
+  const size_t vb = dtype == 0 ? 8 : 16;
+  for (int ci = 0; ci < ncfg; ++ci) {
+    const int tw = cfgs[ci].tw, th = cfgs[ci].th, nl = cfgs[ci].nl;
+    const int nw = (tw / 8) * (th / 8);
+    Q.tw = tw; Q.th = th;
+    P.ntx = (P.W + tw - 1) / tw;
+    P.nty = (P.H + th - 1) / th;
+    P.tiles_per_xcd = (P.ntx * P.nty + 7) / 8;
 
-  // every ray must advance along S in the same direction and not too obliquely; window bound:
-  // bundle cross-section extent (corner rays of every tile) at the two S faces + drift over the
-  // two-slice interval a window covers + texel pair + eps
-  double max_eu = 0, max_ev = 0, max_drift_u = 0, max_drift_v = 0;
-  const double sf[2] = {-0.5, (double)P.N[as] - 0.5};
-  for (int tyi = 0; tyi < P.nty; ++tyi)
-    for (int txi = 0; txi < P.ntx; ++txi) {
-      double umin[2] = {1e300, 1e300}, umax[2] = {-1e300, -1e300}, vmin[2] = {1e300, 1e300}, vmax[2] = {-1e300, -1e300};
-      for (int c = 0; c < 4; ++c) {
-        int ci = std::min(txi * tw + ((c & 1) ? tw - 1 : 0), P.W - 1);
-        int cj = std::min(tyi * th + ((c & 2) ? th - 1 : 0), P.H - 1);
-        double A[3], B[3];
-        host_ray(P, ci, cj, A, B);
-        if (!(B[as] * Q.dir > 0) || fabs(B[as]) < 1e-12) { *why = "rays do not share a marching direction"; return hipErrorNotSupported; }
-        double du = fabs(B[Q.au] / B[as]), dv = fabs(B[Q.av] / B[as]);
-        if (du > 1.5 || dv > 1.5) { *why = "view too oblique for the principal axis"; return hipErrorNotSupported; }
-        max_drift_u = std::max(max_drift_u, du);
-        max_drift_v = std::max(max_drift_v, dv);
+    // every ray must advance along S in the same direction and not too obliquely; window bound:
+    // bundle cross-section extent (corner rays of every tile) at the two S faces + drift over the
+    // two-slice interval a window covers + texel pair + eps
+    double max_eu = 0, max_ev = 0, max_drift_u = 0, max_drift_v = 0;
+    const double sf[2] = {-0.5, (double)P.N[as] - 0.5};
+    for (int tyi = 0; tyi < P.nty; ++tyi)
+      for (int txi = 0; txi < P.ntx; ++txi) {
+        double umin[2] = {1e300, 1e300}, umax[2] = {-1e300, -1e300}, vmin[2] = {1e300, 1e300}, vmax[2] = {-1e300, -1e300};
+        for (int c = 0; c < 4; ++c) {
+          int cx = std::min(txi * tw + ((c & 1) ? tw - 1 : 0), P.W - 1);
+          int cy = std::min(tyi * th + ((c & 2) ? th - 1 : 0), P.H - 1);
+          double A[3], B[3];
+          host_ray(P, cx, cy, A, B);
+          if (!(B[as] * Q.dir > 0) || fabs(B[as]) < 1e-12) { *why = "rays do not share a marching direction"; return hipErrorNotSupported; }
+          double du = fabs(B[Q.au] / B[as]), dv = fabs(B[Q.av] / B[as]);
+          if (du > 1.5 || dv > 1.5) { *why = "view too oblique for the principal axis"; return hipErrorNotSupported; }
+          max_drift_u = std::max(max_drift_u, du);
+          max_drift_v = std::max(max_drift_v, dv);
+          for (int f = 0; f < 2; ++f) {
+            double mm = (sf[f] - A[as]) / B[as];
+            double u = A[Q.au] + B[Q.au] * mm, v = A[Q.av] + B[Q.av] * mm;
+            umin[f] = std::min(umin[f], u); umax[f] = std::max(umax[f], u);
+            vmin[f] = std::min(vmin[f], v); vmax[f] = std::max(vmax[f], v);
+          }
+        }
         for (int f = 0; f < 2; ++f) {
-          double mm = (sf[f] - A[as]) / B[as];
-          double u = A[Q.au] + B[Q.au] * mm, v = A[Q.av] + B[Q.av] * mm;
-          umin[f] = std::min(umin[f], u); umax[f] = std::max(umax[f], u);
-          vmin[f] = std::min(vmin[f], v); vmax[f] = std::max(vmax[f], v);
+          max_eu = std::max(max_eu, umax[f] - umin[f]);
+          max_ev = std::max(max_ev, vmax[f] - vmin[f]);
         }
       }
-      for (int f = 0; f < 2; ++f) {
-        max_eu = std::max(max_eu, umax[f] - umin[f]);
-        max_ev = std::max(max_ev, vmax[f] - vmin[f]);
-      }
-    }
-  // a window spans s in [j-1, j+1] (2 slices of drift; 2.5 at the faces), + pair + eps + rounding
-  int Wu = (int)ceil(max_eu + 2.5 * max_drift_u + 2 * SLAB_EPS) + 3;
-  int Wv = (int)ceil(max_ev + 2.5 * max_drift_v + 2 * SLAB_EPS) + 3;
-  if (dtype == 0) Wu += 2;  // even alignment of both ends
-  Wu = std::min(Wu, Q.Du);
-  Wv = std::min(Wv, Q.Dv);
-  if (Wu < 2 || Wv < 2) { *why = "degenerate window"; return hipErrorNotSupported; }
-  if (Wu > 255 || Wv > 255) { *why = "window too large"; return hipErrorNotSupported; }
-  const int upv = dtype == 0 ? 2 : 1;
-  Q.slot_vox = ((Wu * Wv + 64 * upv - 1) / (64 * upv)) * (64 * upv);
-  Q.chunks = Q.slot_vox / (64 * upv);
-  if (Q.chunks > 63) { *why = "window needs more than 63 DMA chunks"; return hipErrorNotSupported; }
-  // automatic choice (measured, profiles/r01_*): one loader wave issues ~1 KiB of LDS-DMA per
-  // ~250 cycles, so when a tile has to stream more than ~16 B per ray and slice (1024^3 f32 at
-  // one voxel per pixel: 26 B) the gather kernel is still the faster one
-  if (!forced && (double)Q.chunks * 1024.0 / (nw * 64) > 16.0) { *why = "auto: slice windows too heavy per ray for one loader wave"; return hipErrorNotSupported; }
+    // a window spans s in [j-1, j+1] (2 slices of drift; 2.5 at the faces), + pair + eps + rounding
+    int Wu = (int)ceil(max_eu + 2.5 * max_drift_u + 2 * SLAB_EPS) + 3;
+    int Wv = (int)ceil(max_ev + 2.5 * max_drift_v + 2 * SLAB_EPS) + 3;
+    if (dtype == 0) Wu += 2;  // even alignment of both ends
+    Wu = std::min(Wu, Q.Du);
+    Wv = std::min(Wv, Q.Dv);
+    if (Wu < 2 || Wv < 2) { *why = "degenerate window"; return hipErrorNotSupported; }
+    if (Wu > 255 || Wv > 255) { *why = "window too large"; return hipErrorNotSupported; }
+    Q.slot_vox = ((Wu * Wv + 64 * upv - 1) / (64 * upv)) * (64 * upv);
+    Q.chunks = Q.slot_vox / (64 * upv);
+    if (Q.chunks > 63) { *why = "window needs more than 63 DMA chunks"; return hipErrorNotSupported; }
+    // light enough for this configuration?  otherwise try the next (heavier-duty) one
+    if (ci + 1 < ncfg && (double)Q.chunks * 1024.0 / (nw * 64) > 16.0 * nl) continue;
 
-  const size_t vb = dtype == 0 ? 8 : 16;
-  Q.use_ah = (P.third_axis && P.nelts <= 3 && P.sv <= 2048) ? 1 : 0;
-  Q.gmax = opt_T > 0 ? opt_T : 2;
-  const size_t fixed = (size_t)Q.Ds * sizeof(SlabWin) + (4 + 32) * 4 + 64 + (Q.use_ah ? (size_t)P.sv * 4 : 0);
-  // ring: as many slots as fit two workgroups per CU (or one, for big tiles), at least gmax+3
-  const size_t budget = (nw + 1) * 64 > 512 + 64 ? 158 * 1024 : 78 * 1024;
-  int ns = (int)((budget - fixed) / ((size_t)Q.slot_vox * vb));
-  if (ns > 16) ns = 16;
-  if (ns < 4) {
-    ns = (int)((158 * 1024 - fixed) / ((size_t)Q.slot_vox * vb));
-    if (ns > 8) ns = 8;
-  }
-  if (ns < 4) { *why = "window does not fit LDS"; return hipErrorNotSupported; }
-  Q.nslots = ns;
-  if (Q.gmax > ns - 2) Q.gmax = ns - 2;
-  Q.maxfly = std::min(ns - 2, 63 / Q.chunks + 1);
-  if (Q.maxfly < 1) Q.maxfly = 1;
-  if (P.wave_w != 8) Q.maxfly = std::max(1, std::min(P.wave_w, Q.maxfly));  // (experiment knob)
-  const size_t lds = (size_t)ns * Q.slot_vox * vb + fixed;
-#define GO(D, S, R, N) \
-  if (dtype == D && shade_kind == S && Q.perm == R && nw == N) return launch_slab<D, S, R, N>(P, Q, lds, s);
-#define GO_NW(D, S, R) GO(D, S, R, 4) GO(D, S, R, 6) GO(D, S, R, 8) GO(D, S, R, 15)
+    Q.use_ah = (P.third_axis && P.nelts <= 3 && P.sv <= 2048) ? 1 : 0;
+    Q.gmax = std::min(opt_T > 0 ? opt_T : 3, 3);  // <= 3: a consumer step caches 4 slice windows
+    const size_t fixed = (size_t)Q.Ds * sizeof(SlabWin) + (8 + 32) * 4 + 64 + (Q.use_ah ? (size_t)P.sv * 4 : 0);
+    // ring: as many slots as fit two workgroups per CU (small tiles) or one (big tiles)
+    size_t budget = (nw + nl) * 64 > 640 ? 158 * 1024 : 78 * 1024;
+    int ns = (int)((budget - fixed) / ((size_t)Q.slot_vox * vb));
+    if (ns > 16) ns = 16;
+    if (ns < 4) {
+      ns = (int)((158 * 1024 - fixed) / ((size_t)Q.slot_vox * vb));
+      if (ns > 8) ns = 8;
+    }
+    if (ns < 4) { *why = "window does not fit LDS"; return hipErrorNotSupported; }
+    Q.nslots = ns;
+    if (Q.gmax > ns - 2) Q.gmax = ns - 2;
+    const int mych = (Q.chunks + nl - 1) / nl;  // most DMA instructions one loader issues per slice
+    Q.maxfly = std::min(ns - 2, 63 / mych + 1);
+    if (Q.maxfly < 1) Q.maxfly = 1;
+    if (P.wave_w != 8) Q.maxfly = std::max(1, std::min(P.wave_w, Q.maxfly));  // (experiment knob)
+    const size_t lds = (size_t)ns * Q.slot_vox * vb + fixed;
+#define GO(D, S, R, N, L) \
+  if (dtype == D && shade_kind == S && Q.perm == R && nw == N && nl == L) return launch_slab<D, S, R, N, L>(P, Q, lds, s);
+#define GO_NW(D, S, R) GO(D, S, R, 4, 1) GO(D, S, R, 6, 2) GO(D, S, R, 8, 1) GO(D, S, R, 8, 2) GO(D, S, R, 8, 4) GO(D, S, R, 12, 4)
 #define GO_R(D, S) GO_NW(D, S, 0) GO_NW(D, S, 1) GO_NW(D, S, 2)
-  GO_R(0, 0) GO_R(0, 1) GO_R(0, 2) GO_R(1, 0) GO_R(1, 1) GO_R(1, 2)
+    GO_R(0, 0) GO_R(0, 1) GO_R(0, 2) GO_R(1, 0) GO_R(1, 1) GO_R(1, 2)
 #undef GO_R
 #undef GO_NW
 #undef GO
-  *why = "no kernel instance for this tile size";
+    *why = "no kernel instance for this tile size";
+    return hipErrorNotSupported;
+  }
+  (void)forced;
+  *why = "no configuration fits";
   return hipErrorNotSupported;
 }
