@@ -33,6 +33,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, Chip-level parameters)
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch of the ray-march kernel from the PMC passes of THIS command
+    (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs; FETCH_SIZE doubled for gfx950),
+    summarised by tools/summarise_profiles.py into profiles/.  Counters cannot be read from inside
+    the process, so the figure is the committed one for the default workload, or null."""
+    paths = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_traffic.json")) \
+        if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    if not paths:
+        return None
+    with open(os.path.join(ROOT, "profiles", paths[-1])) as f:
+        t = json.load(f)
+    return t.get(workload, {}).get("hbm_bytes_per_launch")
+
+
 def load_package():
     name = "simian_spacemonkey_amd"
     if name in sys.modules:
@@ -261,6 +275,7 @@ def main():
         t, kms, kn = timed(r, a.steps, a.warmup, frame, world, cstate)
     kernel, _, alg_bytes = r.last_frame_info()
     ms = t / a.steps * 1e3
+    default_workload = (n, size, planes) == (512, 1024, 512)
     samples = float(size) * size * planes
     out = {
         "metric": "Msamples/s + fps, 512^3 VGH vol @1024^2 x 512 steps",
@@ -278,7 +293,8 @@ def main():
     if rank == 0:
         ach = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                           "frac": ach / HBM_PEAK_GBPS,
+                           "traffic": pmc_traffic("cfg3") if default_workload and world == 1 else None,
                            "kernel_ms": kms, "kernel_frames_timed": kn,
                            "algorithmic_bytes_per_launch": alg_bytes,
                            "note": "this rank's shard; %d^3 f32 working set is VALU/LDS-bound by "
@@ -306,7 +322,9 @@ def main():
             "workload": "cfg4 single GPU: %d^3 f32 VGH + u8 normals, (v,g)x(h) TF, R8k Phong, %dx%dx%d" % (nn_, size, size, planes),
             "ms_per_frame": t2 / k2 * 1e3, "fps": k2 / t2, "Msamples_per_s": samples / (t2 / k2) / 1e6,
             "roofline": {"bound": "hbm", "achieved": ach2, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": ach2 / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": kms2,
+                         "frac": ach2 / HBM_PEAK_GBPS,
+                         "traffic": pmc_traffic("north_star") if default_workload and nn_ == 1024 else None,
+                         "kernel_ms": kms2,
                          "algorithmic_bytes_per_launch": alg2},
             "kernel": {1: "gather", 2: "slab-staged"}.get(kernel2, str(kernel2))}
     if rank == 0:

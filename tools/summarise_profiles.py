@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 outputs merged into gpurun_out/ into the committed summaries in profiles/.
+
+  python tools/summarise_profiles.py <tag> <kernel-trace dir> <FETCH_SIZE pmc dir> <WRITE_SIZE pmc dir>
+
+Writes profiles/<tag>_kernel_stats.csv (copy of rocprofv3 --stats), profiles/<tag>_pmc.txt and
+profiles/<tag>_traffic.json (per-launch HBM bytes of the ray-march kernels, FETCH_SIZE doubled as
+MI355X_MICROARCH.md prescribes for gfx950; bench.py quotes it as roofline.traffic)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def pmc(d, name):
+    out = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == name:
+                out[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    tag, kt, fd, wd = sys.argv[1:5]
+    prof = os.path.join(ROOT, "profiles")
+    for f in glob.glob(os.path.join(kt, "*", "*_kernel_stats.csv")):
+        shutil.copy(f, os.path.join(prof, tag + "_kernel_stats.csv"))
+    fetch, write = pmc(fd, "FETCH_SIZE"), pmc(wd, "WRITE_SIZE")
+    traffic = {}
+    with open(os.path.join(prof, tag + "_pmc.txt"), "w") as fo:
+        fo.write("# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) around `python3 bench.py --steps 5 --warmup 1 --no-cpu`\n")
+        fo.write("# per-dispatch values in KiB as reported; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 on gfx950\n")
+        fo.write("# (FETCH_SIZE tallies 128-B requests at 64 B; calibrated on smk_k_pack<1>: known 16.11 GB read <-> 8.05 GB reported)\n")
+        for k in sorted(set(fetch) | set(write)):
+            f_, w_ = fetch.get(k, []), write.get(k, [])
+            fo.write("%-70s n=%3d FETCH min %.6g max %.6g | WRITE min %.6g max %.6g\n" % (
+                k[:70], len(f_), min(f_ or [0]), max(f_ or [0]), min(w_ or [0]), max(w_ or [0])))
+            if "smk_k_slab" in k or "smk_k_gather" in k:
+                traffic[k] = {"fetch_kib": f_, "write_kib": w_}
+    # bench.py uses one kernel instance per workload (light config for 512^3, heavy for 1024^3)
+    res = {}
+    for k, v in traffic.items():
+        f_, w_ = v["fetch_kib"], v["write_kib"] or [0]
+        if f_:
+            res[k] = {"hbm_bytes_per_launch": (2 * sum(f_) / len(f_) + sum(w_) / len(w_)) * 1024,
+                      "fetch_size_kib_mean": sum(f_) / len(f_), "write_size_kib_mean": sum(w_) / len(w_),
+                      "launches": len(f_)}
+    # the default bench.py run marches two volumes: the smaller traffic belongs to the headline
+    # workload (512^3), the larger to the north-star one (1024^3)
+    order = sorted(res, key=lambda k: res[k]["hbm_bytes_per_launch"])
+    if len(order) == 2:
+        res = {"cfg3": dict(res[order[0]], kernel=order[0]), "north_star": dict(res[order[1]], kernel=order[1])}
+    json.dump(res, open(os.path.join(prof, tag + "_traffic.json"), "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
