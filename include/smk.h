@@ -153,6 +153,14 @@ int smk_last_frame_info(smk_ctx *ctx, int *kernel, float *ms, double *alg_bytes)
  * average (ms) over the last min(N,64) frames.  smk_timing_read synchronises the device. */
 int smk_timing_reset(smk_ctx *ctx);
 int smk_timing_read(smk_ctx *ctx, float *avg_ms, int *nframes);
+/* named counters of the last frame (developer statistics, no reference counterpart):
+ * "slab_iters", "slab_active_lanes", "slab_inside_lanes", "slab_hit_lanes" (collected when option
+ * lockstep has bit 16 set), "slab_status".  Synchronises the device. */
+int smk_get_stat(smk_ctx *ctx, const char *name, double *value);
+/* workgroup timeline of the last frame rendered with option lockstep bit 32 (developer tool):
+ * records of 4 x uint32 {start, end (100 MHz ticks), HW_ID, XCC_ID | tile<<8 | slices<<20};
+ * *nrecords = records available; copies min(cap_records, *nrecords) when out != NULL. */
+int smk_get_trace(smk_ctx *ctx, unsigned *out, int cap_records, int *nrecords);
 /* effective 2-D TF after opacity correction, as uploaded (sg*sv*4 bytes) */
 int smk_get_tf2d_effective(smk_ctx *ctx, unsigned char *out, float *rate_out);
 

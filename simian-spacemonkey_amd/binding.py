@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "smk_set_tf2d", "smk_set_tf3d", "smk_set_camera", "smk_set_shading", "smk_set_sampling",
     "smk_set_perturb", "smk_render", "smk_render_device", "smk_composite_over_device",
     "smk_make_vgh_device", "smk_normals_vgh_device", "smk_synth_volume_device",
-    "smk_get_raycoef", "smk_set_option", "smk_last_frame_info", "smk_get_tf2d_effective",
+    "smk_get_raycoef", "smk_set_option", "smk_last_frame_info", "smk_get_stat", "smk_get_trace", "smk_get_tf2d_effective",
     "smk_timing_reset", "smk_timing_read",
 ]
 
@@ -51,7 +51,8 @@ class RayCoef(C.Structure):
 
 
 def library_path():
-    return os.path.join(_CSRC, "libsmk_hip.so")
+    # SMK_LIB: developer override (kernel experiments build variant libraries side by side)
+    return os.environ.get("SMK_LIB") or os.path.join(_CSRC, "libsmk_hip.so")
 
 
 def build_library(force=False):
@@ -108,6 +109,8 @@ def load_library():
     L.smk_get_raycoef.argtypes = [C.c_void_p, P(RayCoef)]
     L.smk_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     L.smk_last_frame_info.argtypes = [C.c_void_p, P(C.c_int), P(C.c_float), P(C.c_double)]
+    L.smk_get_stat.argtypes = [C.c_void_p, C.c_char_p, P(C.c_double)]
+    L.smk_get_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int, P(C.c_int)]
     L.smk_get_tf2d_effective.argtypes = [C.c_void_p, C.c_void_p, P(C.c_float)]
     L.smk_timing_reset.argtypes = [C.c_void_p]
     L.smk_timing_read.argtypes = [C.c_void_p, P(C.c_float), P(C.c_int)]
@@ -279,6 +282,19 @@ class Renderer:
         k, ms, b = C.c_int(0), C.c_float(0), C.c_double(0)
         self._ck(self.L.smk_last_frame_info(self.ctx, C.byref(k), C.byref(ms), C.byref(b)))
         return k.value, ms.value, b.value
+
+    def stat(self, name):
+        v = C.c_double(0)
+        self._ck(self.L.smk_get_stat(self.ctx, name.encode(), C.byref(v)))
+        return v.value
+
+    def trace(self):
+        n = C.c_int(0)
+        self._ck(self.L.smk_get_trace(self.ctx, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 0), 4), dtype=np.uint32)
+        if n.value > 0:
+            self._ck(self.L.smk_get_trace(self.ctx, out.ctypes.data, n.value, C.byref(n)))
+        return out
 
     def timing_reset(self):
         self._ck(self.L.smk_timing_reset(self.ctx))

@@ -80,6 +80,10 @@ extern "C" void smk_destroy(smk_ctx *c) {
   void *ptrs[] = {c->d_tlut, c->d_tf_vg, c->d_tf_h, c->d_tf3d, c->d_noise, c->d_out, c->d_depth};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
+  if (c->slab.h_status) (void)hipHostFree(c->slab.h_status);
+  if (c->slab.d_diag) (void)hipFree(c->slab.d_diag);
+  if (c->slab.d_order) (void)hipFree(c->slab.d_order);
+  if (c->slab.d_trace) (void)hipFree(c->slab.d_trace);
   for (hipEvent_t e : c->tev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->tev1) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -640,6 +644,51 @@ extern "C" int smk_timing_read(smk_ctx *c, float *avg_ms, int *nframes) {
   return 0;
 }
 
+// slice-ring kernel error word -> failed call (the kernel never hangs and never returns a frame
+// built from unloaded data silently)
+static int check_slab_status(smk_ctx *c) {
+  if (!c->slab.h_status) return 0;
+  int st = *(volatile int *)c->slab.h_status;
+  if (!st) return 0;
+  *(volatile int *)c->slab.h_status = 0;
+  FAIL(c, "slice-ring kernel reported %s (status %d); frame invalid", st == 1 ? "a producer/consumer time-out" : "a window outside its host bound", st);
+}
+
+extern "C" int smk_get_stat(smk_ctx *c, const char *name, double *value) {
+  if (!c || !name || !value) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  static const char *diag_names[9] = {"slab_iters", "slab_active_lanes", "slab_inside_lanes", "slab_hit_lanes",
+                                      "slab_loader_issue_kcyc", "slab_loader_wait_kcyc", "slab_loader_blocked_kcyc", "slab_loader_total_kcyc",
+                                      "slab_iters_with_hit"};
+  for (int k = 0; k < 9; ++k)
+    if (!strcmp(name, diag_names[k])) {
+      float v = 0.f;
+      if (c->slab.d_diag) {
+        HIPCHK(c, hipDeviceSynchronize());
+        HIPCHK(c, hipMemcpy(&v, c->slab.d_diag + k, 4, hipMemcpyDeviceToHost));
+      }
+      *value = v;
+      return 0;
+    }
+  if (!strcmp(name, "slab_status")) {
+    HIPCHK(c, hipDeviceSynchronize());
+    *value = c->slab.h_status ? *(volatile int *)c->slab.h_status : 0;
+    return 0;
+  }
+  FAIL(c, "smk_get_stat: unknown name '%s'", name);
+}
+
+extern "C" int smk_get_trace(smk_ctx *c, unsigned *out, int cap_records, int *nrecords) {
+  if (!c || !nrecords) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  *nrecords = c->slab.d_trace ? c->slab.trace_n : 0;
+  if (out && *nrecords > 0) {
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(out, c->slab.d_trace, (size_t)std::min(cap_records, *nrecords) * 16, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
 extern "C" int smk_last_frame_info(smk_ctx *c, int *kernel, float *ms, double *alg_bytes) {
   if (!c) return 1;
   if (kernel) *kernel = c->last_kernel;
@@ -665,6 +714,7 @@ static int build_params(smk_ctx *c, RenderParams &P) {
     P.lo[a] = (float)c->g0[a] - 0.5f;
     P.hi[a] = (float)c->g1[a] - 0.5f;
     P.top[a] = c->g1[a] == c->N[a];
+    P.hin[a] = P.top[a] ? P.hi[a] : nextafterf(P.hi[a], -INFINITY);
     P.invN[a] = 1.0f / (float)c->N[a];
   }
   P.nelts = c->nelts;
@@ -787,13 +837,21 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
   c->last_kernel = 1;
   c->slab_why.clear();
   if (c->opt_kernel != 1 && c->tf_mode == 1) {
+    if (!c->slab.h_status) {
+      HIPCHK(c, hipHostMalloc((void **)&c->slab.h_status, sizeof(int), hipHostMallocMapped));
+      *c->slab.h_status = 0;
+      HIPCHK(c, hipMalloc((void **)&c->slab.d_diag, 16 * sizeof(float)));
+    }
+    if (check_slab_status(c)) return 1;  // an earlier asynchronous frame failed
+    if (c->opt_lockstep & 16) HIPCHK(c, hipMemsetAsync(c->slab.d_diag, 0, 16 * sizeof(float), s));
     const char *why = nullptr;
     const int forced = c->opt_kernel == 2;
     hipError_t e = smk_launch_slab(P, c->dtype, shade_kind_of(c), c->opt_slab_T, c->opt_tile, forced, c->d_vox,
-                                   c->d_vox_x, &why, s);
+                                   c->d_vox_x, &c->slab, &why, s);
     if (e == hipErrorNotSupported && why && !strcmp(why, "x-major copy unavailable")) {
       if (make_xmajor_copy(c)) return 1;
-      e = smk_launch_slab(P, c->dtype, shade_kind_of(c), c->opt_slab_T, c->opt_tile, forced, c->d_vox, c->d_vox_x, &why, s);
+      e = smk_launch_slab(P, c->dtype, shade_kind_of(c), c->opt_slab_T, c->opt_tile, forced, c->d_vox, c->d_vox_x,
+                          &c->slab, &why, s);
     }
     if (e == hipSuccess) c->last_kernel = 2;
     else if (e == hipErrorNotSupported) {
@@ -828,6 +886,7 @@ extern "C" int smk_render(smk_ctx *c, float *rgba, float *depth) {
   if (smk_render_device(c, c->d_out, depth ? c->d_depth : nullptr, c->stream)) return 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+  if (check_slab_status(c)) return 1;
   HIPCHK(c, hipMemcpy(rgba, c->d_out, npix * 16, hipMemcpyDeviceToHost));
   if (depth) HIPCHK(c, hipMemcpy(depth, c->d_depth, npix * 4, hipMemcpyDeviceToHost));
   return 0;

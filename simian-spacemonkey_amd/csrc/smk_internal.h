@@ -24,6 +24,7 @@ struct RenderParams {
   int D[3];             // stored dims (region + halo)
   float lo[3], hi[3];   // region in voxel coordinates: [g0-.5, g1-.5)
   int top[3];           // region touches the volume's top face on this axis (inclusive)
+  float hin[3];         // largest coordinate that is inside: hi on a top face, else the float below hi
   float invN[3];
   int nelts;
   int n_in_w;  // f32: normal bits live in .w
@@ -54,6 +55,17 @@ struct RenderParams {
   // ---- tile mapping
   int ntx, nty, tiles_per_xcd;
   int wave_w, blk_w, lockstep;  // gather-kernel tiling knobs (smk_set_option)
+};
+
+// side buffers of the slice-ring kernel, owned by the context
+struct SlabAux {
+  int *h_status = nullptr;      // pinned, device-visible: error word (0 = ok)
+  float *d_diag = nullptr;      // [16] diagnostic counters (option lockstep bit 16)
+  int *d_order = nullptr;       // tile schedule of the current camera
+  int order_cap = 0;
+  std::vector<int> order_host;  // what d_order holds
+  unsigned *d_trace = nullptr;  // [trace_n][4] workgroup timeline of the last traced frame (option lockstep bit 32)
+  int trace_cap = 0, trace_n = 0;
 };
 
 struct smk_ctx {
@@ -123,6 +135,7 @@ struct smk_ctx {
   // options / stats
   int opt_kernel = 0, opt_slab_T = 0, opt_tf_raw = 0, opt_tile = 0;
   int opt_wave_w = 8, opt_blk_w = 2, opt_lockstep = 1;
+  SlabAux slab;  // slice-ring kernel side buffers
   int last_kernel = 0;
   float last_ms = 0;
   double last_alg_bytes = 0;
@@ -133,5 +146,5 @@ hipError_t smk_launch_gather(const RenderParams &P, int dtype, int tf_mode, int 
                              hipStream_t s);
 // returns hipErrorNotSupported (and *why) when the frame must use the gather kernel
 hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T, int opt_tile, int forced,
-                           const void *vox_native, const void *vox_xmajor, const char **why,
+                           const void *vox_native, const void *vox_xmajor, SlabAux *aux, const char **why,
                            hipStream_t s);

@@ -31,6 +31,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "smk_device.h"
 
@@ -41,15 +42,22 @@ struct SlabParams {
   long long strideV, strideS;  // voxel strides of the layout in use (U stride is 1)
   int Ou, Ov, Os;              // stored-box origin along U,V,S (global voxel index)
   int Du, Dv, Ds;              // stored-box dims along U,V,S
-  int slot_vox;                // LDS voxels per ring slot (a whole number of 64-lane DMA chunks)
-  int chunks;                  // DMA wave-instructions per slice (= slot_vox / (64*UPV)), uniform
-  int gmax;                    // base slices a consumer may take per step
+  int wu;                      // 16-byte units per window row that are loaded (<= 1 << wp_log2)
+  int wv;                      // window rows that are loaded
+  int wp_log2;                 // LDS row pitch = (1 << wp_log2) units: one DMA chunk = 64 >> wp_log2 whole rows
+  int chunks;                  // DMA wave-instructions per slice = ceil(wv / rows per chunk), uniform
+  int slot_bytes;              // chunks * 1024
   int nslots;                  // ring size
-  int maxfly;                  // slices the loader keeps in flight (chunks*(maxfly-1) <= 63)
+  int maxfly;                  // slices a loader keeps in flight ((maxfly-1) * its chunks <= 63)
+  int kband;                   // a lane may run at most this many positions ahead of its wave's slowest lane
   int dir;                     // +1: rays advance towards +S, -1: towards -S
   int tw, th;                  // pixel tile
   const void *vox;             // layout base (native or x-major)
   int use_ah;                  // third-axis alpha served from a 1-D LDS table (<= 3 channels)
+  const int *order;            // tile of each block (work-balanced schedule, -1 = none), see smk_launch_slab
+  int *status;                 // host-visible word: 1 = protocol time-out, 2 = window bound violated
+  float *diag;                 // [16] diagnostic counters (lockstep bit 16) or null
+  unsigned *trace;             // [nblocks][4] per-workgroup {start, end (100 MHz ticks), HW_ID, XCC_ID} (lockstep bit 32) or null
 };
 
 #define SLAB_EPS 0.02f
@@ -66,49 +74,48 @@ struct VoxT<1> {
   typedef float4 type;
 };
 
-template <int DT>
-__device__ __forceinline__ SmkCorner slab_corner(const typename VoxT<DT>::type &v) {
-  SmkCorner k;
-  if (DT == 0) {
-    const uint2 &q = reinterpret_cast<const uint2 &>(v);
-    k.c0 = smk_ub(q.x, 0);
-    k.c1 = smk_ub(q.x, 1);
-    k.c2 = smk_ub(q.x, 2);
-    k.c3 = smk_ub(q.x, 3);
-    k.nb = q.y;
-  } else {
-    const float4 &q = reinterpret_cast<const float4 &>(v);
-    k.c0 = q.x;
-    k.c1 = q.y;
-    k.c2 = q.z;
-    k.c3 = 0.0f;
-    k.nb = __float_as_uint(q.w);
-  }
-  return k;
-}
+typedef float v2f __attribute__((ext_vector_type(2)));
 
-// window of one slice for this tile, in stored-box voxel coordinates; the slot holds it flat,
-// row-major with pitch w (so one DMA wave-instruction = 64 consecutive 16-byte units)
-struct SlabWin {
-  short u0, v0;
-  unsigned char w, h;  // window dims (<= 255, host-checked)
-  short slot;          // ring slot of the slice
+// The 8 corners of one sample as ONE batch of LDS reads behind ONE wait.  Written as asm: left
+// to hipcc the reads are either split into partial ds_read2_b32 pieces per use or (behind an
+// optimisation barrier) waited for one by one -- 8 LDS round trips per sample.  a/b = byte
+// addresses of corner (u,v) in the two slices, ap/bp = the same one row up; +VB = one voxel on.
+// Only the channels classification needs are read here (2 or 3 floats / the 4 data bytes); the
+// packed normals follow in a second batch for the samples that turn out to be visible: 16-24
+// instead of 32 VGPRs live across the batch, and less LDS traffic for the transparent majority.
+typedef float v3f __attribute__((ext_vector_type(3)));
+#define SLAB_READ8(INS, OFF)                                                                                              \
+  asm volatile(INS " %0, %8\n\t" INS " %1, %8 offset:" OFF "\n\t" INS " %2, %9\n\t" INS " %3, %9 offset:" OFF "\n\t"       \
+               INS " %4, %10\n\t" INS " %5, %10 offset:" OFF "\n\t" INS " %6, %11\n\t" INS " %7, %11 offset:" OFF "\n\t"  \
+               "s_waitcnt lgkmcnt(0)"                                                                                     \
+               : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3]), "=&v"(q[4]), "=&v"(q[5]), "=&v"(q[6]), "=&v"(q[7])   \
+               : "v"(a), "v"(ap), "v"(b), "v"(bp)                                                                         \
+               : "memory")
+// f32 voxels {c0, c1, c2, normal bits}: first two / three channels
+__device__ __forceinline__ void slab_read8(unsigned a, unsigned ap, unsigned b, unsigned bp, v2f (&q)[8]) { SLAB_READ8("ds_read_b64", "16"); }
+__device__ __forceinline__ void slab_read8(unsigned a, unsigned ap, unsigned b, unsigned bp, v3f (&q)[8]) { SLAB_READ8("ds_read_b96", "16"); }
+// u8 voxels {4 data bytes, normal bits}: the data dword
+__device__ __forceinline__ void slab_read8_u8(unsigned a, unsigned ap, unsigned b, unsigned bp, uint32_t (&q)[8]) { SLAB_READ8("ds_read_b32", "8"); }
+// the packed normals of the same 8 corners (dword NOFF of the voxel)
+__device__ __forceinline__ void slab_read8_nb16(unsigned a, unsigned ap, unsigned b, unsigned bp, uint32_t (&q)[8]) {
+  a += 12; ap += 12; b += 12; bp += 12;
+  SLAB_READ8("ds_read_b32", "16");
+}
+__device__ __forceinline__ void slab_read8_nb8(unsigned a, unsigned ap, unsigned b, unsigned bp, uint32_t (&q)[8]) {
+  a += 4; ap += 4; b += 4; bp += 4;
+  SLAB_READ8("ds_read_b32", "8");
+}
+#undef SLAB_READ8
+
+// per-slice table entry: where the slice's window sits in the ring and in the volume
+struct SlabEnt {
+  int base;      // LDS byte address of GLOBAL voxel (u=0, v=0) of this slice's slot image:
+                 // corner address = base + v * pitch_bytes + u * voxel_bytes
+  short u0, v0;  // window origin in stored-box voxel coordinates (loader)
 };
 
-// one LDS voxel read as a single ds_read_b128 / b64: the empty asm keeps hipcc from splitting
-// the vector load into partial ds_read2_b32 pieces per consumer
-__device__ __forceinline__ float4 lds_vox(const float4 *p) {
-  float4 v = *p;
-  asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-  return v;
-}
-__device__ __forceinline__ uint2 lds_vox(const uint2 *p) {
-  uint2 v = *p;
-  asm volatile("" : "+v"(v.x), "+v"(v.y));
-  return v;
-}
-
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
+typedef __attribute__((address_space(3))) char *lds_cptr_w;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
 
 // s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
@@ -148,37 +155,78 @@ __device__ __forceinline__ uint2 raw_lds_b64(const void *p) {
   asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
   return v;
 }
-
 __device__ __forceinline__ void raw_lds_st_b32(void *p, int v) {
   unsigned a = (unsigned)(size_t)(lds_cptr_t)p;
   asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
 }
 
+// minimum over the 64 lanes of a fully active wave, on the DPP network (no LDS traffic)
+__device__ __forceinline__ int wave_min_i32(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));  // row_half_mirror
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));  // row_mirror
+  // every row of 16 lanes now holds its own minimum
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// bilinear RGBA8 lookup like smk_tex2d, for tables of >= 2x2 texels: the clamped texel pair is
+// always (i, i+1) then, so the four texels are two 8-byte loads at a 32-bit offset
+struct SlabTexel4 {
+  uint32_t a, b, c, d;
+  float fs, ft;
+};
+__device__ __forceinline__ SlabTexel4 slab_tex2d_fetch(const uint32_t *tex, int ss, int st, float s, float t) {
+  int s0, s1, t0, t1;
+  SlabTexel4 o;
+  smk_lin_clamp(__fmaf_rn(s, (float)ss, -0.5f), ss, s0, s1, o.fs);
+  smk_lin_clamp(__fmaf_rn(t, (float)st, -0.5f), st, t0, t1, o.ft);
+  const unsigned off = (unsigned)(t0 * ss + s0) * 4u;
+  const char *tb = reinterpret_cast<const char *>(tex);
+  uint2 lo, hi;
+  __builtin_memcpy(&lo, tb + off, 8);
+  __builtin_memcpy(&hi, tb + (off + (unsigned)ss * 4u), 8);
+  o.a = lo.x;
+  o.b = lo.y;
+  o.c = hi.x;
+  o.d = hi.y;
+  return o;
+}
+__device__ __forceinline__ float slab_tex_chan(const SlabTexel4 &x, int k) {
+  return smk_lerp(smk_lerp(smk_ub(x.a, k), smk_ub(x.b, k), x.fs), smk_lerp(smk_ub(x.c, k), smk_ub(x.d, k), x.fs), x.ft) * SMK_INV255;
+}
+
 // NW = consumer waves (64 rays each), NL = loader waves; the block has (NW+NL)*64 threads, the
-// last NL waves are loaders: loader l streams DMA chunks l, l+NL, ... of every slice
+// last NL waves are loaders: loader l streams DMA chunks l, l+NL, ... of every slice.
 // second launch-bound = waves per SIMD wanted: workgroups of 5/9/10 waves only double up on a CU
 // (2 x 9 waves = 5 on one SIMD) if the kernel stays within 96 VGPRs
-template <int DT, int SH, int PERM, int NW, int NL>
-__global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9 || (NW + NL) == 5 || (NW + NL) == 10) ? 5 : 4) void smk_k_slab(const RenderParams P, const SlabParams Q) {
+template <int DT, int SH, int PERM, int NW, int NL, bool DIAG>
+__global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) == 5 || (NW + NL) == 10) ? 5 : ((NW + NL) == 11 ? 3 : 4)) void smk_k_slab(const RenderParams P, const SlabParams Q) {
   typedef typename VoxT<DT>::type Vox;
-  constexpr int UPV = DT == 0 ? 2 : 1;  // voxels per 16-byte DMA unit
+  constexpr int UPV = DT == 0 ? 2 : 1;   // voxels per 16-byte DMA unit
+  constexpr int VB = DT == 0 ? 8 : 16;   // bytes per voxel
+  constexpr int VBL = DT == 0 ? 3 : 4;   // log2
   constexpr int NTH = (NW + NL) * 64;
   extern __shared__ __align__(16) unsigned char smem[];
-  // LDS carve: ring [nslots][slot_vox] voxels | window table [Ds] | control words | alpha_H
-  Vox *ring = reinterpret_cast<Vox *>(smem);
-  const int slot_vox = Q.slot_vox;
-  SlabWin *wtab = reinterpret_cast<SlabWin *>(smem + (size_t)Q.nslots * slot_vox * sizeof(Vox));
-  // control words: [0] smin [1] smax [3] protocol time-out [4..4+NL) landed per loader [8..8+NW) progress
-  int *ctl = reinterpret_cast<int *>(wtab + Q.Ds);
+  // LDS carve: ring [nslots][slot_bytes] | slice table [Ds] | control words | alpha_H
+  SlabEnt *wtab = reinterpret_cast<SlabEnt *>(smem + (size_t)Q.nslots * Q.slot_bytes);
+  // control words: [0] smin [1] smax [3] error flag [4..4+NL) landed per loader [8..8+NW) progress
+  int *ctl = reinterpret_cast<int *>(smem + (((size_t)Q.nslots * Q.slot_bytes + (size_t)Q.Ds * sizeof(SlabEnt) + 15) & ~(size_t)15));
   // third-axis alpha as a 1-D table: with <= 3 channels the (H,4th) lookup has t = 0, i.e. row
   // 0 of deptex2 with a zero t-weight, so lerp(row0[s0], row0[s1], fs) is the SAME float
   float *ah = reinterpret_cast<float *>(ctl + 8 + 32);
 
-  int tx, ty;
-  if (!smk_tile_of_block(P, blockIdx.x, tx, ty)) return;  // whole workgroup leaves together
+  const int tile = Q.order[blockIdx.x];
+  if (tile < 0) return;  // whole workgroup leaves together
+  const bool tracing = DIAG && Q.trace != nullptr && (P.lockstep & 32);  // (diagnostic: workgroup timeline)
+  unsigned trace_t0 = 0;
+  if (tracing) trace_t0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+  const int ty = tile / P.ntx, tx = tile - ty * P.ntx;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: roles and loops stay wave-uniform
   const bool is_loader = wave >= NW;
   const int lid = wave - NW;  // loader index
   // consumer wave = 8x8 pixel sub-tile; waves laid out row-major over the tile
@@ -213,6 +261,38 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9 || (NW + NL) == 5 |
   int m = (int)floorf(fmaxf(tenter, 0.0f));
   int m1 = (int)ceilf(fminf(texit, (float)(rc.nplanes - 1)));
   if (empty || !(tenter <= texit)) m1 = m - 1;
+  // Exact first/last inside sample.  A coordinate fma(q, B, A) is monotone in q (one correctly
+  // rounded operation), so the samples that pass the membership predicate of the gather kernel
+  // -- lo <= p <= hin on every axis, hin = hi itself on a top face, else the float just below
+  // it -- form ONE interval of q; the conservative range above brackets it with a few planes of
+  // slack, so testing its ends here removes the per-sample test from the marching loop.
+#ifndef SLAB_NO_INTERVAL
+  {
+    auto inside = [&](int q) -> bool {
+      const float qf = (float)q;
+      const float p0 = __fmaf_rn(qf, B[0], A[0]), p1 = __fmaf_rn(qf, B[1], A[1]), p2 = __fmaf_rn(qf, B[2], A[2]);
+      return ((int)(smk_clampf(p0, P.lo[0], P.hin[0]) == p0) & (int)(smk_clampf(p1, P.lo[1], P.hin[1]) == p1) &
+              (int)(smk_clampf(p2, P.lo[2], P.hin[2]) == p2)) != 0;
+    };
+    int mf = m1 + 1, ml = m - 1;
+    int qa = m, qb = m1;
+    // (the ends move inwards until they are inside; rays that only graze the region end empty)
+    while (true) {
+      const bool go_a = qa <= m1 && mf > m1, go_b = qb >= m && ml < m;
+      if (!__any(go_a || go_b)) break;  // (a few steps: the slack is +-2 planes)
+      if (go_a) {
+        if (inside(qa)) mf = qa;
+        ++qa;
+      }
+      if (go_b) {
+        if (inside(qb)) ml = qb;
+        --qb;
+      }
+    }
+    m = mf;  // (no inside sample at all: mf = m1 + 1 > ml, the ray is empty)
+    m1 = ml;
+  }
+#endif
 
   constexpr int AS = PERM == 0 ? 2 : (PERM == 1 ? 1 : 0);
   constexpr int AU = PERM == 2 ? 1 : 0;
@@ -230,8 +310,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9 || (NW + NL) == 5 |
   if (tid == 0) {
     ctl[0] = 0x7fffffff;
     ctl[1] = -0x7fffffff;
-    ctl[3] = 0;  // protocol time-out flag (bounded spins)
-    ctl[4] = ctl[5] = ctl[6] = ctl[7] = 0;
+    ctl[3] = 0;  // error flag (bounded spins, window bound)
+    for (int l = 0; l < 4; ++l) ctl[4 + l] = l < NL ? 0 : 0x7fffffff;  // absent loaders never hold anyone back
   }
   if (tid < 32) ctl[8 + tid] = SLAB_DONE;
   __syncthreads();
@@ -254,12 +334,17 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9 || (NW + NL) == 5 |
   __syncthreads();
   const int smin = ctl[0], smax = ctl[1];
   const int dir = Q.dir, nslots = Q.nslots;
+  const int wp_log2 = Q.wp_log2;
+  const int pitch_log2 = wp_log2 + 4;  // LDS row pitch in bytes = 16 << wp_log2
+  const unsigned ring_addr = (unsigned)(size_t)(lds_cptr_t)smem;
   // positions p = 0..npos-1 in marching order: base slice b(p) = dir>0 ? smin+p : smax-p;
   // load order q = 0..npos: slice L(q) = dir>0 ? smin+q : smax+1-q; position p reads L(p), L(p+1)
   const int npos = smax - smin + 1;
-  // ---- per-slice windows of this tile (every thread fills some table entries): bbox over the
-  // tile's 4 corner rays of every position a sample touching slice sl can have (s in
-  // [sl-1, sl+1], stretched to the volume faces at the ends)
+  // ---- per-slice windows of this tile (every thread fills some table entries).  Every window
+  // has the SAME shape (Q.wu units x Q.wv rows, host-sized to cover the widest bundle section)
+  // so a DMA lane's source offset inside the window never changes; only its origin moves: the
+  // bbox, over the tile's 4 corner rays, of every position a sample touching slice sl can have
+  // (s in [sl-1, sl+1], stretched to the volume faces at the ends)
   if (npos > 0) {
     float cA[4][3], cB[4][3];
 #pragma unroll
@@ -275,6 +360,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9 || (NW + NL) == 5 |
     }
     if (Q.use_ah)
       for (int e = tid; e < P.sv; e += NTH) ah[e] = smk_ub(P.tf_h[e], 3);
+    const int wuv = Q.wu * UPV;  // window width in voxels
     for (int q = tid; q <= npos; q += NTH) {
       int sl = dir > 0 ? smin + q : smax + 1 - q;  // global slice index
       int e = sl - Q.Os;
@@ -298,294 +384,391 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9 || (NW + NL) == 5 |
       int u1 = (int)floorf(fminf(fmaxf(umax + SLAB_EPS, 0.0f), (float)(NU - 2))) + 1;
       int v0 = (int)floorf(fminf(fmaxf(vmin - SLAB_EPS, 0.0f), (float)(NV - 2)));
       int v1 = (int)floorf(fminf(fmaxf(vmax + SLAB_EPS, 0.0f), (float)(NV - 2))) + 1;
-      // to stored-box coordinates, clipped to it; rows made of whole 16-byte units
+      // to stored-box coordinates, clipped to it
       u0 = max(u0 - Q.Ou, 0);
       v0 = max(v0 - Q.Ov, 0);
       u1 = min(u1 - Q.Ou, Q.Du - 1);
       v1 = min(v1 - Q.Ov, Q.Dv - 1);
-      if (UPV == 2) {
-        u0 &= ~1;
-        u1 |= 1;  // the stored U extent is even (host check)
-      }
-
-      int w = max(u1 - u0 + 1, 0), h = max(v1 - v0 + 1, 0);
-      if (w * h > slot_vox) h = w > 0 ? slot_vox / w : 0;  // never overrun a slot (host sizes it)
-      SlabWin ww;
-      ww.u0 = (short)u0;
-      ww.v0 = (short)v0;
-      ww.w = (unsigned char)w;
-      ww.h = (unsigned char)h;
-      ww.slot = (short)(q % nslots);
-      wtab[e] = ww;
+      if (UPV == 2) u0 &= ~1;  // rows start on whole 16-byte units (the stored U extent is even)
+      // fixed-shape window: slide it back inside the stored box where it would stick out
+      const int wu0 = min(u0, Q.Du - wuv), wv0 = min(v0, Q.Dv - Q.wv);
+      if (u1 - wu0 + 1 > wuv || v1 - wv0 + 1 > Q.wv) ctl[3] = 2;  // host bound violated: reported, never silent
+      SlabEnt ent;
+      ent.u0 = (short)wu0;
+      ent.v0 = (short)wv0;
+      ent.base = (int)ring_addr + (q % nslots) * Q.slot_bytes - ((Q.Ov + wv0) << pitch_log2) - (Q.Ou + wu0) * VB;
+      wtab[e] = ent;
     }
   }
   // every consumer wave announces the first position it needs before anyone moves on
-  int bs = (m <= m1) ? base_slice(m) : -0x40000000;
-  auto pos_of = [&](int b) -> int { return dir > 0 ? b - smin : smax - b; };
+  const int psgn = dir > 0 ? 1 : -1, poff = dir > 0 ? -smin : smax;  // position of base slice b = psgn*b + poff
+  int pb = SLAB_DONE;  // position of this ray's next sample
+  if (m <= m1) pb = psgn * base_slice(m) + poff;
   int pos = SLAB_DONE;
   if (!is_loader && npos > 0) {
-    int p0 = (m <= m1) ? pos_of(bs) : SLAB_DONE;
-    for (int o = 32; o > 0; o >>= 1) p0 = min(p0, __shfl_xor(p0, o));
-    pos = p0;
+    pos = wave_min_i32(pb);
     if (lane == 0) ctl[8 + wave] = pos;
   }
   __syncthreads();  // table, alpha_H, control words visible; LAST workgroup barrier
   float C0 = 0.f, C1 = 0.f, C2 = 0.f, C3 = 0.f;
-  float first = __int_as_float(0x7f800000);
 
   if (npos > 0) {
     if (is_loader) {
       // ================================ loader wave ============================================
       // Streams load indices q = 0..npos in order.  Slot of q is q % nslots; it may be rewritten
       // once every consumer is past position q - nslots (positions < min progress are done).
-      // Every slice issues exactly `chunks` DMA instructions (lanes past the window re-read
-      // the window's first unit into the slot's unused tail), so the in-order vmcnt tells
-      // which slices have landed: `inflight` slices outstanding <=> vmcnt <= chunks*inflight.
+      // Every slice is exactly `chunks` DMA wave-instructions (one chunk = 64 >> wp_log2 whole
+      // window rows), so the in-order vmcnt tells which slices have landed.  A lane's source
+      // offset inside the window is the same for every chunk and every slice, so a chunk costs
+      // the wave ~8 scalar instructions + one global_load_lds: measured with tools/dma_probe.hip,
+      // ONE such wave per CU streams 5.2-5.9 TB/s chip-wide (94-104 cycles per KiB), while a
+      // compiler-scheduled loop with per-lane address arithmetic stays at ~415 cycles per KiB
+      // whatever the memory behind it -- instruction issue, not HBM, is what a loader must save.
       __builtin_amdgcn_s_setprio(3);  // the stream must never wait for issue slots behind pollers
       const char *gv = reinterpret_cast<const char *>(Q.vox);
       const int chunks = Q.chunks;
       const int mych = (chunks - lid + NL - 1) / NL;  // DMA instructions THIS loader issues per slice
+      const bool has_last = (chunks - 1) % NL == lid;  // ... the last of which may be the slice's short chunk
+      const int nfull = has_last ? mych - 1 : mych;
       const unsigned strideVb = (unsigned)(Q.strideV * (long long)sizeof(Vox));  // bytes, < 2^32
-      int q = 0, inflight = 0, landed = 0, idle = 0, minp = 0;
-      long long t_issue = 0, t_wait = 0, t_idle = 0, t_all = __builtin_amdgcn_s_memtime(), t0_ = 0;
-      const bool prof = (P.lockstep & 4) != 0;  // (diagnostic build switch: loader cycle shares)
+      const int rpc = 64 >> wp_log2;                                             // window rows per chunk
+      const int lrow = lane >> wp_log2, lcol = lane & ((1 << wp_log2) - 1);
+      const bool full_ok = lcol < Q.wu;                                    // lanes beyond the window width never load
+      const bool last_ok = full_ok && (chunks - 1) * rpc + lrow < Q.wv;    // nor rows beyond its height (last chunk)
+      const unsigned voff = (unsigned)lrow * strideVb + (unsigned)lcol * 16u;
+      const size_t cstep = (size_t)(NL * rpc) * strideVb;  // source advance from one of my chunks to the next
+      const size_t strideSb = (size_t)Q.strideS * sizeof(Vox);
+      const bool l2hot = DIAG && (P.lockstep & 8) != 0;           // (diagnostic: every slice re-reads one slice)
+      int q = 0, inflight = 0, landed = 0, idle = 0, minp = 0, slot_q = 0;
+      if (DIAG && (P.lockstep & 64)) minp = 0x3ffffff0;  // (diagnostic: free-running stream, nobody consumes)
+      // progress words, read by lane 0 alone (NW <= 16 words as four b128 reads)
       auto poll_progress = [&]() -> int {
         int v = SLAB_DONE;
-        if (lane < NW) v = raw_lds_b32(&ctl[8 + lane]);
-        for (int o = 16; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-        return __builtin_amdgcn_readfirstlane(v);
+        if (lane < 16) v = raw_lds_b32(&ctl[8 + lane]);  // words >= NW stay at SLAB_DONE
+        v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+        v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+        v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+        v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+        return __builtin_amdgcn_readlane(v, 0);
       };
+      // one LDS-DMA wave-instruction: 16 B per active lane from src + voff to LDS dst + lane*16
+      // (saddr form: no per-chunk VALU; M0 written in the statement that reads it)
+      unsigned keep_m0;
+#define SLAB_DMA(src_, dst_)                                                                                        \
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" \
+               : "=&s"(keep_m0)                                                                                     \
+               : "v"(voff), "s"(dst_), "s"(src_)                                                                    \
+               : "memory")
+      // table entries of 64 consecutive load indices, one per lane, refreshed every 64 slices:
+      // a slice's window origin is then one v_readlane away instead of an LDS round trip
+      int ent_uv = 0;
+      const bool prof = DIAG && (P.lockstep & 16) != 0 && Q.diag != nullptr;  // (diagnostic: where a loader's cycles go)
+      long long t_issue = 0, t_wait = 0, t_idle = 0, t_mark = 0;
+      const long long t_start = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
       while (landed <= npos) {
         // ---- issue while the ring has room (progress is re-polled only when it blocks us)
         bool stop = false;
-        if (prof) t0_ = __builtin_amdgcn_s_memtime();
+        if (prof) t_mark = __builtin_amdgcn_s_memtime();
         while (q <= npos && inflight < Q.maxfly) {
           if (q - nslots >= minp) {
             minp = poll_progress();
+            if (DIAG && (P.lockstep & 64)) minp = 0x3ffffff0;
             if (minp >= SLAB_DONE) {  // every consumer finished: the rest is not needed
               stop = true;
               break;
             }
             if (q - nslots >= minp) break;
           }
-          const int sl = (dir > 0 ? smin + q : smax + 1 - q) - Q.Os;
-          if (sl >= 0 && sl < Q.Ds) {
-            SlabWin w;
-            {
-              uint2 raw = raw_lds_b64(&wtab[sl]);
-              memcpy(&w, &raw, sizeof w);
-            }
-            const int wu = max(w.w / UPV, 1);  // 16-byte units per window row
-            const int n = (w.w / UPV) * w.h;   // units in the window
-            Vox *dst = ring + w.slot * slot_vox;
-            // wave-uniform 64-bit base of the window + a 32-bit per-lane byte offset
-            // (diagnostic bit 8: every slice re-reads slice 0 -> L2-hot stream, isolates issue cost)
-            const size_t sl_src = (P.lockstep & 8) ? 0 : (size_t)sl;
-            const char *base = gv + (sl_src * Q.strideS + (size_t)w.v0 * Q.strideV + (size_t)w.u0) * sizeof(Vox);
-            // this loader's chunks c = lid, lid+NL, ...; lane's unit idx = 64*c + lane =
-            // row*wu + col, advanced incrementally by 64*NL units per step
-            const int adv = 64 * NL;
-            const int qa = adv / wu, ra = adv - qa * wu;
-            const int idx0 = lid * 64 + lane;
-            const int row0 = idx0 / wu;
-            int col = idx0 - row0 * wu;
-            unsigned off = (unsigned)row0 * strideVb + (unsigned)col * 16u;
-            const unsigned step = (unsigned)qa * strideVb + (unsigned)ra * 16u;
-            const unsigned wrap = strideVb - (unsigned)wu * 16u;
-            int left = n - idx0;  // > 0 while this lane's unit is inside the window
-            for (int c = lid; c < chunks; c += NL) {
-              const unsigned o = left > 0 ? off : 0u;
-              // LDS address = wave-uniform base + lane*16: the slot image is flat in unit order
-              __builtin_amdgcn_global_load_lds((glb_ptr_t)(base + o), (lds_ptr_t)(dst + c * 64 * UPV), 16, 0, 0);
-              left -= adv;
-              col += ra;
-              off += step;
-              if (col >= wu) {
-                col -= wu;
-                off += wrap;
+          if ((q & 63) == 0) {
+            const int ql = q + lane;
+            const int e = (dir > 0 ? smin + ql : smax + 1 - ql) - Q.Os;
+            ent_uv = -1;
+            if (ql <= npos && e >= 0 && e < Q.Ds) ent_uv = (int)raw_lds_b64(&wtab[e]).y;
+          }
+          const int uv = __builtin_amdgcn_readlane(ent_uv, q & 63);
+          const unsigned dst0 = ring_addr + (unsigned)(slot_q * Q.slot_bytes + lid * 1024);
+          if (uv != -1) {
+            const int sl = (dir > 0 ? smin + q : smax + 1 - q) - Q.Os;
+            const unsigned u0 = (unsigned)uv & 0xffffu, v0 = (unsigned)uv >> 16;
+            const char *src = gv + (l2hot ? (size_t)0 : (size_t)sl * strideSb) + (size_t)(v0 * strideVb + u0 * (unsigned)VB) +
+                              (size_t)(lid * rpc) * strideVb;
+            if (full_ok) {
+              const char *sp = src;
+              unsigned dp = dst0;
+              int k = nfull;
+              for (; k >= 4; k -= 4) {
+                SLAB_DMA(sp, dp); sp += cstep; dp += NL * 1024;
+                SLAB_DMA(sp, dp); sp += cstep; dp += NL * 1024;
+                SLAB_DMA(sp, dp); sp += cstep; dp += NL * 1024;
+                SLAB_DMA(sp, dp); sp += cstep; dp += NL * 1024;
               }
+              if (k & 2) {
+                SLAB_DMA(sp, dp); sp += cstep; dp += NL * 1024;
+                SLAB_DMA(sp, dp); sp += cstep; dp += NL * 1024;
+              }
+              if (k & 1) SLAB_DMA(sp, dp);
+            }
+            if (has_last && last_ok) {  // (operands recomputed from uniform values: sp/dp above live in a divergent region)
+              const char *sl_src = src + (size_t)nfull * cstep;
+              const unsigned sl_dst = dst0 + (unsigned)(nfull * NL * 1024);
+              SLAB_DMA(sl_src, sl_dst);
             }
           } else {
             // slice outside the stored box (never read): keep the instruction count uniform
-            for (int c = lid; c < chunks; c += NL)
-              __builtin_amdgcn_global_load_lds((glb_ptr_t)gv, (lds_ptr_t)(ring + (q % nslots) * slot_vox + c * 64 * UPV), 16, 0, 0);
+            unsigned dst = dst0;
+            for (int c = lid; c < chunks; c += NL) {
+              SLAB_DMA(gv, dst);
+              dst += NL * 1024;
+            }
           }
           ++q;
           ++inflight;
+          if (++slot_q == nslots) slot_q = 0;
         }
-        if (prof) t_issue += __builtin_amdgcn_s_memtime() - t0_;
+        if (prof) {
+          const long long t = __builtin_amdgcn_s_memtime();
+          t_issue += t - t_mark;
+          t_mark = t;
+        }
         if (stop) break;
         if (inflight > 0) {
           // retire the oldest slice in flight: all but the (inflight-1) younger slices' DMAs done
-          if (prof) t0_ = __builtin_amdgcn_s_memtime();
           wait_vmcnt(mych * (inflight - 1));
-          if (prof) t_wait += __builtin_amdgcn_s_memtime() - t0_;
           --inflight;
           ++landed;
           raw_lds_st_b32(&ctl[4 + lid], landed);
+          if (prof) t_wait += (long long)__builtin_amdgcn_s_memtime() - t_mark;
         } else {
-          if (prof) t_idle += 200;
           if (++idle > (1 << 22) || raw_lds_b32(&ctl[3])) {  // bounded spin (see consumers)
             raw_lds_st_b32(&ctl[3], 1);
             break;
           }
-          __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_s_sleep(1);
+          if (prof) t_idle += (long long)__builtin_amdgcn_s_memtime() - t_mark;
         }
       }
+#undef SLAB_DMA
       wait_vmcnt(0);
-      if (prof && lane == 0) {
-        t_all = __builtin_amdgcn_s_memtime() - t_all;
-        P.out[P.W * (size_t)P.H - 1 - blockIdx.x] = make_float4((float)t_issue, (float)t_wait, (float)t_idle, (float)t_all);
+      if (prof && lane == 0 && lid == 0) {
+        atomicAdd(&Q.diag[4], (float)t_issue * 1e-3f);
+        atomicAdd(&Q.diag[5], (float)t_wait * 1e-3f);
+        atomicAdd(&Q.diag[6], (float)t_idle * 1e-3f);
+        atomicAdd(&Q.diag[7], (float)((long long)__builtin_amdgcn_s_memtime() - t_start) * 1e-3f);
       }
     } else {
       // ================================ consumer waves ==========================================
+      // One sample per lane and iteration.  A lane takes its next sample as soon as the two
+      // slices it touches have landed; the wave's progress is the position of its slowest lane.
+      // While data is ahead of the wave every unfinished lane is active in every iteration (a
+      // fixed slice step per iteration would leave the lanes without a sample in it idle).
       // slices landed = the slowest loader's count
+      // (one 16-byte LDS read per poll: the four words are adjacent and aligned)
       auto landed_all = [&]() -> int {
-        int v = lds_ld(&ctl[4]);
-#pragma unroll
-        for (int l = 1; l < NL; ++l) v = min(v, lds_ld(&ctl[4 + l]));
-        return v;
+        int4 v;
+        const unsigned a = (unsigned)(size_t)(lds_cptr_t)(ctl + 4);
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+        return min(min(v.x, v.y), min(v.z, v.w));
       };
-      int have = 0;  // cached copy of `landed` (monotonic): re-polled only when it is too small
-      while (pos < npos) {
-        if (!__any(m <= m1)) break;  // every ray of this wave is finished
-        // wait until the slices of position pos (load indices pos, pos+1) have landed; take up
-        // to gmax positions if more are already resident
-        if (have < pos + 1 + Q.gmax) have = landed_all();
-        for (int spins = 0; have < pos + 2; ++spins) {
-          if (spins > (1 << 22) || lds_ld(&ctl[3])) {  // bounded: never hang the GPU on a protocol bug
-            lds_st(&ctl[3], 1);
-            have = 0x3ffffff0;
-            pos = npos;
-            break;
+      const bool stream_only = DIAG && (P.lockstep & 2) != 0;  // (diagnostic: consume nothing)
+      if (DIAG && (P.lockstep & 64)) pb = SLAB_DONE;   // (diagnostic: free-running stream)
+      const bool count = DIAG && (P.lockstep & 16) != 0 && Q.diag != nullptr;
+      float n_it = 0.f, n_act = 0.f, n_in = 0.f, n_hit = 0.f, n_anyhit = 0.f;
+      int have = 0;  // cached copy of `landed` (monotonic): re-polled only when a lane is blocked on it
+      // table row of the sample's base slice: entry index = bs - Os = psgn*pb + (-psgn*poff - Os)
+      const int eoff = -psgn * poff - Q.Os;
+      const unsigned wtab_addr = (unsigned)(size_t)(lds_cptr_t)wtab;
+      const unsigned pitch_b = 16u << wp_log2;
+      for (int it = 0;; ++it) {
+        const bool want = pb < SLAB_DONE;
+        if (!__any(want)) break;  // every ray of this wave is finished
+        // progress = position of the slowest lane, published every other iteration (the DPP
+        // reduction is ~12 VALU; a stale value only delays slot recycling by one step)
+#ifndef SLAB_PROGRESS_MASK
+#define SLAB_PROGRESS_MASK 1
+#endif
+        if (!(it & SLAB_PROGRESS_MASK)) {
+          const int plo = wave_min_i32(pb);
+          if (plo != pos) {  // positions below plo are done: their lower slices may be recycled
+            pos = plo;       // (every slot read of earlier iterations has returned: slab_read8 waits)
+            if (lane == 0) lds_st(&ctl[8 + wave], pos);
           }
-          __builtin_amdgcn_s_sleep(4);
+        }
+        // (kband: the slices between the wave's slowest and fastest lane stay resident, so a
+        //  narrow band leaves more of a small ring to the loaders at the price of idle lanes)
+        const int ptop = pos + Q.kband;
+        bool act = want && pb + 2 <= have && pb <= ptop;
+        if (__any(want && pb <= ptop && !act)) {
           have = landed_all();
-        }
-        if (pos >= npos) break;
-        have = __builtin_amdgcn_readfirstlane(have);
-        asm volatile("" ::: "memory");  // slot reads stay behind the poll
-        const int G = min(min(Q.gmax, have - pos - 1), npos - pos);
-        const int b0 = dir > 0 ? smin + pos : smax - pos - G + 1, b1 = b0 + G - 1;
-        // windows of slices b0 .. b1+1 (at most 4): wave-uniform, fetched once per step into SGPRs
-        // so a sample's address does not start with a dependent LDS round trip
-        uint2 we[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const uint2 raw = *reinterpret_cast<const uint2 *>(&wtab[min(b0 + k, smax + 1) - Q.Os]);
-          we[k].x = __builtin_amdgcn_readfirstlane(raw.x);
-          we[k].y = __builtin_amdgcn_readfirstlane(raw.y);
-        }
-        // ---- all samples of this ray whose base slice lies in [b0, b1]
-        // (a two-phase variant -- walk to the next alpha>0 sample, then shade all lanes together --
-        //  was measured 1.45x SLOWER on the LevWidget scene: hits are not sparse enough there)
-        while (true) {
-          const bool act = bs >= b0 && bs <= b1 && !(P.lockstep & 2);  // (debug bit 2: stream only)
-          if (!__any(act)) break;
-          if (act) {
-            float p[3];
-            p[0] = __fmaf_rn((float)m, B[0], A[0]);
-            p[1] = __fmaf_rn((float)m, B[1], A[1]);
-            p[2] = __fmaf_rn((float)m, B[2], A[2]);
-            // same membership predicate as the gather kernel, evaluated without short-circuit
-            // branches (bitwise on lane masks)
-            const bool t0 = P.top[0] != 0, t1 = P.top[1] != 0, t2 = P.top[2] != 0;
-            bool in = ((p[0] >= P.lo[0]) & ((p[0] < P.hi[0]) | (t0 & (p[0] <= P.hi[0])))) &
-                      ((p[1] >= P.lo[1]) & ((p[1] < P.hi[1]) | (t1 & (p[1] <= P.hi[1])))) &
-                      ((p[2] >= P.lo[2]) & ((p[2] < P.hi[2]) | (t2 & (p[2] <= P.hi[2]))));
-            if (in) {
-              int x0, x1, y0, y1, z0, z1;
-              float fx, fy, fz;
-              smk_lin_clamp(p[0], P.N[0], x0, x1, fx);
-              smk_lin_clamp(p[1], P.N[1], y0, y1, fy);
-              smk_lin_clamp(p[2], P.N[2], z0, z1, fz);
-              const int iu = (AU == 0 ? x0 : y0) - Q.Ou, iv = (AV == 1 ? y0 : z0) - Q.Ov;
-              const int is = (AS == 2 ? z0 : (AS == 1 ? y0 : x0));
-              const int kk = is - b0;  // 0 .. G-1 (G <= 3)
-              const uint2 ea = kk == 0 ? we[0] : (kk == 1 ? we[1] : we[2]);
-              const uint2 eb = kk == 0 ? we[1] : (kk == 1 ? we[2] : we[3]);
-              SlabWin wa, wb;
-              memcpy(&wa, &ea, sizeof wa);
-              memcpy(&wb, &eb, sizeof wb);
-              // clamp into the resident windows (never alters a result: windows cover the bundle)
-              const int ca = min(max(iu - wa.u0, 0), wa.w - 2), ra = min(max(iv - wa.v0, 0), wa.h - 2);
-              const int cb = min(max(iu - wb.u0, 0), wb.w - 2), rb = min(max(iv - wb.v0, 0), wb.h - 2);
-              const Vox *sa = ring + (wa.slot * slot_vox + ra * wa.w + ca);
-              const Vox *sb = ring + (wb.slot * slot_vox + rb * wb.w + cb);
-              // corners q[ds][dv][du]
-              SmkCorner q000 = slab_corner<DT>(lds_vox(sa)), q001 = slab_corner<DT>(lds_vox(sa + 1));
-              SmkCorner q010 = slab_corner<DT>(lds_vox(sa + wa.w)), q011 = slab_corner<DT>(lds_vox(sa + wa.w + 1));
-              SmkCorner q100 = slab_corner<DT>(lds_vox(sb)), q101 = slab_corner<DT>(lds_vox(sb + 1));
-              SmkCorner q110 = slab_corner<DT>(lds_vox(sb + wb.w)), q111 = slab_corner<DT>(lds_vox(sb + wb.w + 1));
-              // back to model order k<dx><dy><dz>: the lerp order (x, y, z) is the gather kernel's
-#define KX(dx, dy, dz)                                                                                   \
-  (PERM == 0 ? (dz ? (dy ? (dx ? q111 : q110) : (dx ? q101 : q100)) : (dy ? (dx ? q011 : q010) : (dx ? q001 : q000))) \
-   : PERM == 1 ? (dy ? (dz ? (dx ? q111 : q110) : (dx ? q101 : q100)) : (dz ? (dx ? q011 : q010) : (dx ? q001 : q000))) \
-               : (dx ? (dz ? (dy ? q111 : q110) : (dy ? q101 : q100)) : (dz ? (dy ? q011 : q010) : (dy ? q001 : q000))))
-              const SmkCorner &k000 = KX(0, 0, 0), &k100 = KX(1, 0, 0), &k010 = KX(0, 1, 0), &k110 = KX(1, 1, 0);
-              const SmkCorner &k001 = KX(0, 0, 1), &k101 = KX(1, 0, 1), &k011 = KX(0, 1, 1), &k111 = KX(1, 1, 1);
-#undef KX
-              const float sc = DT == 0 ? SMK_INV255 : 1.0f;
-              float ch0 = SMK_TRI(c0), ch1 = SMK_TRI(c1), ch2 = 0.f, ch3 = 0.f;
-              if (DT == 0) {
-                ch0 *= sc;
-                ch1 *= sc;
-              }
-              if (P.third_axis) {
-                ch2 = SMK_TRI(c2);
-                if (DT == 0) ch2 *= sc;
-                if (DT == 0 && P.nelts == 4) ch3 = SMK_TRI(c3) * sc;
-              }
-              float4 col;
-              bool hit;
-              if (Q.use_ah) {
-                col = smk_tex2d(P.tf_vg, P.sv, P.sg, ch0, ch1);
-                int h0, h1;
-                float fh;
-                smk_lin_clamp(__fmaf_rn(ch2, (float)P.sv, -0.5f), P.sv, h0, h1, fh);
-                col.w *= smk_lerp(ah[h0], ah[h1], fh) * SMK_INV255;
-                col.w = smk_sat(col.w);
-                hit = col.w != 0.0f;
-              } else {
-                hit = smk_classify<DT, 1>(P, ch0, ch1, ch2, ch3, col);
-              }
-              if (hit) {
-                float4 src;
-                if (SH == 0) {
-                  src = smk_shade_sample<0>(P, col, 0.f, 0.f, 0.f, 0.f);
-                } else {
-                  float n0 = smk_nrm(k000.nb, k100.nb, k010.nb, k110.nb, k001.nb, k101.nb, k011.nb, k111.nb, 0, fx, fy, fz);
-                  float n1 = smk_nrm(k000.nb, k100.nb, k010.nb, k110.nb, k001.nb, k101.nb, k011.nb, k111.nb, 1, fx, fy, fz);
-                  float n2 = smk_nrm(k000.nb, k100.nb, k010.nb, k110.nb, k001.nb, k101.nb, k011.nb, k111.nb, 2, fx, fy, fz);
-                  src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1);
-                }
-                float w = 1.0f - C3;
-                if (first == __int_as_float(0x7f800000)) first = __fmaf_rn((float)m, rc.dtau, rc.tau0) * P.znear;
-                C0 = __fmaf_rn(w, src.x, C0);
-                C1 = __fmaf_rn(w, src.y, C1);
-                C2 = __fmaf_rn(w, src.z, C2);
-                C3 = __fmaf_rn(w, src.w, C3);
-                // exact early termination: once A == 1.0f every later weight (1-A) is exactly 0,
-                // so no later sample can change C or A (nor the first-hit depth)
-                if (C3 == 1.0f) m1 = m;
-              }
+          if (!__any(want && pb + 2 <= have && pb <= ptop)) {
+            // nobody can move: make sure `pos` is this wave's true minimum, then wait for its slices
+            const int plo = wave_min_i32(pb);
+            if (plo != pos) {
+              pos = plo;
+              if (lane == 0) lds_st(&ctl[8 + wave], pos);
             }
-            ++m;
-            bs = (m <= m1) ? base_slice(m) : -0x40000000;
+            for (int spins = 0; have < pos + 2; ++spins) {
+              if (spins > (1 << 22) || lds_ld(&ctl[3])) {  // bounded: never hang the GPU on a protocol bug
+                lds_st(&ctl[3], 1);
+                have = 0x3ffffff0;
+                m1 = m - 1;
+                pb = SLAB_DONE;
+                break;
+              }
+              // (backing off further for waves whose first slice is many slices away was measured
+              //  slower: reaction time matters more than the polls' issue slots)
+              __builtin_amdgcn_s_sleep(2);
+              have = landed_all();
+            }
           }
+          have = __builtin_amdgcn_readfirstlane(have);
+          act = pb < SLAB_DONE && pb + 2 <= have && pb <= pos + Q.kband;
         }
-        // done with positions [pos, pos+G): their lower slices may be recycled
-        pos += G;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every slot read has returned
-        if (lane == 0) lds_st(&ctl[8 + wave], pos);
+        asm volatile("" ::: "memory");  // slot reads stay behind the poll
+        bool d_hit = false;  // (diagnostic counters only)
+        if (act && !stream_only) {
+          // the two slices' slot images (one 8-byte table entry each, adjacent): issued first,
+          // the position arithmetic below covers the LDS round trip
+          const int *te = reinterpret_cast<const int *>(smem + (wtab_addr - ring_addr)) + 2 * (psgn * pb + eoff);
+          const int base_a = te[0], base_b = te[2];
+          const float mf = (float)m;
+          const float p0 = __fmaf_rn(mf, B[0], A[0]), p1 = __fmaf_rn(mf, B[1], A[1]), p2 = __fmaf_rn(mf, B[2], A[2]);
+          // (no membership test: [m, m1] is exactly the inside interval, see the set-up)
+          int x0, x1, y0, y1, z0, z1;
+          float fx, fy, fz;
+          smk_lin_clamp(p0, P.N[0], x0, x1, fx);
+          smk_lin_clamp(p1, P.N[1], y0, y1, fy);
+          smk_lin_clamp(p2, P.N[2], z0, z1, fz);
+          const int iu = AU == 0 ? x0 : y0, iv = AV == 1 ? y0 : z0;  // global voxel indices
+          const unsigned lo_off = ((unsigned)iv << pitch_log2) + ((unsigned)iu << VBL);
+          const unsigned a0 = (unsigned)base_a + lo_off, b0 = (unsigned)base_b + lo_off;
+          // corners <ds><dv><du> -> model order <dx><dy><dz>; lerp order x, y, z like the gather kernel
+#define QI(dx, dy, dz) (PERM == 0 ? ((dz) * 4 + (dy) * 2 + (dx)) : PERM == 1 ? ((dy) * 4 + (dz) * 2 + (dx)) : ((dx) * 4 + (dz) * 2 + (dy)))
+#define TRI(E)                                                                                                             \
+  smk_lerp(smk_lerp(smk_lerp(E(0, 0, 0), E(1, 0, 0), fx), smk_lerp(E(0, 1, 0), E(1, 1, 0), fx), fy),                       \
+           smk_lerp(smk_lerp(E(0, 0, 1), E(1, 0, 1), fx), smk_lerp(E(0, 1, 1), E(1, 1, 1), fx), fy), fz)
+          float ch0, ch1, ch2 = 0.f, ch3 = 0.f;
+          if constexpr (DT == 1) {
+            if (P.third_axis) {
+              v3f q[8];
+              slab_read8(a0, a0 + pitch_b, b0, b0 + pitch_b, q);
+#define E0(dx, dy, dz) q[QI(dx, dy, dz)].x
+#define E1(dx, dy, dz) q[QI(dx, dy, dz)].y
+#define E2(dx, dy, dz) q[QI(dx, dy, dz)].z
+              ch0 = TRI(E0);
+              ch1 = TRI(E1);
+              ch2 = TRI(E2);
+#undef E2
+            } else {
+              v2f q[8];
+              slab_read8(a0, a0 + pitch_b, b0, b0 + pitch_b, q);
+              ch0 = TRI(E0);
+              ch1 = TRI(E1);
+#undef E1
+#undef E0
+            }
+          } else {
+            uint32_t q[8];
+            slab_read8_u8(a0, a0 + pitch_b, b0, b0 + pitch_b, q);
+#define E0(dx, dy, dz) smk_ub(q[QI(dx, dy, dz)], 0)
+#define E1(dx, dy, dz) smk_ub(q[QI(dx, dy, dz)], 1)
+#define E2(dx, dy, dz) smk_ub(q[QI(dx, dy, dz)], 2)
+#define E3(dx, dy, dz) smk_ub(q[QI(dx, dy, dz)], 3)
+            ch0 = TRI(E0) * SMK_INV255;
+            ch1 = TRI(E1) * SMK_INV255;
+            if (P.third_axis) {
+              ch2 = TRI(E2) * SMK_INV255;
+              if (P.nelts == 4) ch3 = TRI(E3) * SMK_INV255;
+            }
+#undef E3
+#undef E2
+#undef E1
+#undef E0
+          }
+#undef TRI
+          float4 col;
+          bool hit;
+          SlabTexel4 tx4 = {0, 0, 0, 0, 0.f, 0.f};
+          if (Q.use_ah) {
+            // alpha first (all four (V,G) texels are needed for it anyway); colour only on a hit
+            tx4 = slab_tex2d_fetch(P.tf_vg, P.sv, P.sg, ch0, ch1);
+            int h0, h1;
+            float fh;
+            smk_lin_clamp(__fmaf_rn(ch2, (float)P.sv, -0.5f), P.sv, h0, h1, fh);
+            col.w = slab_tex_chan(tx4, 3) * (smk_lerp(ah[h0], ah[h0 + 1], fh) * SMK_INV255);
+            col.w = smk_sat(col.w);
+            hit = col.w != 0.0f;
+          } else {
+            hit = smk_classify<DT, 1>(P, ch0, ch1, ch2, ch3, col);
+          }
+          d_hit = hit;
+          if (hit) {
+            if (Q.use_ah) {
+              col.x = slab_tex_chan(tx4, 0);
+              col.y = slab_tex_chan(tx4, 1);
+              col.z = slab_tex_chan(tx4, 2);
+            }
+            float4 src;
+            if (SH == 0) {
+              src = smk_shade_sample<0>(P, col, 0.f, 0.f, 0.f, 0.f);
+            } else {
+              uint32_t nb[8];  // second batch: the packed normals of the same corners
+              if (DT == 1) slab_read8_nb16(a0, a0 + pitch_b, b0, b0 + pitch_b, nb);
+              else slab_read8_nb8(a0, a0 + pitch_b, b0, b0 + pitch_b, nb);
+#define NB(dx, dy, dz) nb[QI(dx, dy, dz)]
+              float n0 = smk_nrm(NB(0, 0, 0), NB(1, 0, 0), NB(0, 1, 0), NB(1, 1, 0), NB(0, 0, 1), NB(1, 0, 1), NB(0, 1, 1), NB(1, 1, 1), 0, fx, fy, fz);
+              float n1 = smk_nrm(NB(0, 0, 0), NB(1, 0, 0), NB(0, 1, 0), NB(1, 1, 0), NB(0, 0, 1), NB(1, 0, 1), NB(0, 1, 1), NB(1, 1, 1), 1, fx, fy, fz);
+              float n2 = smk_nrm(NB(0, 0, 0), NB(1, 0, 0), NB(0, 1, 0), NB(1, 1, 0), NB(0, 0, 1), NB(1, 0, 1), NB(0, 1, 1), NB(1, 1, 1), 2, fx, fy, fz);
+#undef NB
+              src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1);
+            }
+            float w = 1.0f - C3;
+            C0 = __fmaf_rn(w, src.x, C0);
+            C1 = __fmaf_rn(w, src.y, C1);
+            C2 = __fmaf_rn(w, src.z, C2);
+            C3 = __fmaf_rn(w, src.w, C3);
+            // exact early termination: once A == 1.0f every later weight (1-A) is exactly 0,
+            // so no later sample can change C or A
+            if (C3 == 1.0f) m1 = m;
+          }
+#undef QI
+        }
+        if (act) {
+          ++m;
+          pb = (m <= m1) ? psgn * base_slice(m) + poff : SLAB_DONE;
+        }
+        if (count) {
+          n_it += 1.f;
+          n_act += (float)__popcll(__ballot(act));
+          n_in += (float)__popcll(__ballot(act));
+          n_hit += (float)__popcll(__ballot(d_hit));
+          n_anyhit += __any(d_hit) ? 1.f : 0.f;
+        }
       }
       if (lane == 0) lds_st(&ctl[8 + wave], SLAB_DONE);
+      if (count && lane == 0) {
+        atomicAdd(&Q.diag[0], n_it);
+        atomicAdd(&Q.diag[1], n_act);
+        atomicAdd(&Q.diag[2], n_in);
+        atomicAdd(&Q.diag[3], n_hit);
+        atomicAdd(&Q.diag[8], n_anyhit);
+      }
     }
   }
   if (live) {
     size_t o = (size_t)j * P.W + i;
     P.out[o] = make_float4(C0, C1, C2, C3);
-    if (P.depth) P.depth[o] = first;
+  }
+  // errors are reported, never swallowed: the host turns a non-zero status into a failed frame
+  if (npos > 0) {
+    __syncthreads();
+    if (tid == 0 && ctl[3]) *(volatile int *)Q.status = ctl[3];
+  }
+  if (tracing && tid == 0) {
+    unsigned *t = Q.trace + 4 * (size_t)blockIdx.x;
+    t[0] = trace_t0;
+    t[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
+    t[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+    t[3] = (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) | ((unsigned)tile << 8) | ((unsigned)max(npos, 0) << 20);  // XCC_ID, tile, slices
   }
 }
 
@@ -600,24 +783,26 @@ static void host_ray(const RenderParams &P, int i, int j, double A[3], double B[
   }
 }
 
-template <int DT, int SH, int PERM, int NW, int NL>
-static hipError_t launch_slab(const RenderParams &P, const SlabParams &Q, size_t lds, hipStream_t s) {
-  auto k = smk_k_slab<DT, SH, PERM, NW, NL>;
+template <int DT, int SH, int PERM, int NW, int NL, bool DIAG>
+static hipError_t launch_slab(const RenderParams &P, const SlabParams &Q, size_t lds, int nblocks, hipStream_t s) {
+  auto k = smk_k_slab<DT, SH, PERM, NW, NL, DIAG>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(k, dim3(8 * P.tiles_per_xcd), dim3((NW + NL) * 64), lds, s, P, Q);
+  hipLaunchKernelGGL(k, dim3(nblocks), dim3((NW + NL) * 64), lds, s, P, Q);
   return hipGetLastError();
 }
 
 // plan + launch; returns hipErrorNotSupported when the configuration must use the gather kernel
 hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T, int opt_tile, int forced,
-                           const void *vox_native, const void *vox_xmajor, const char **why, hipStream_t s) {
+                           const void *vox_native, const void *vox_xmajor, SlabAux *aux, const char **why,
+                           hipStream_t s) {
   *why = nullptr;
   if (P.pert_on) { *why = "perturbation"; return hipErrorNotSupported; }
+  if (P.depth) { *why = "first-hit depth requested"; return hipErrorNotSupported; }  // (a register the fast path cannot spare)
   if (P.N[0] < 2 || P.N[1] < 2 || P.N[2] < 2) { *why = "volume thinner than 2 voxels"; return hipErrorNotSupported; }
   if (dtype == 1 && !P.n_in_w) { *why = "4-channel f32 voxels"; return hipErrorNotSupported; }
   if (P.rc.nplanes <= 0) { *why = "no planes"; return hipErrorNotSupported; }
@@ -630,6 +815,8 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     if (fabs(Bc[a]) > fabs(Bc[as])) as = a;
   SlabParams Q;
   memset(&Q, 0, sizeof Q);
+  Q.status = aux->h_status;
+  Q.diag = aux->d_diag;
   Q.as = as;
   if (as == 2) { Q.perm = 0; Q.au = 0; Q.av = 1; }
   else if (as == 1) { Q.perm = 1; Q.au = 0; Q.av = 2; }
@@ -646,22 +833,26 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
   if (dtype == 0 && ((Q.Du & 1) || (Q.strideV & 1) || (Q.strideS & 1))) { *why = "odd U extent for 8-byte voxels"; return hipErrorNotSupported; }
 
   // workgroup shape: consumer waves are 8x8 pixel sub-tiles; NL loader waves.
-  //   light windows (<= ~16 B per ray and slice): 32x16 tile, 8+1 waves, two workgroups per CU
-  //   heavy windows (1024^3 f32 at a voxel per pixel: 26 B): 32x24 tile, 12+4 waves, one per CU
-  // (one loader wave issues ~1 KiB of LDS-DMA per ~250 cycles incl. its address arithmetic:
-  //  profiles/r01_*; so the stream needs several loader waves per CU to approach HBM speed)
+  //   light windows: 32x16 tile, 8+1 waves, two workgroups per CU
+  //   heavy windows (1024^3 f32 at a voxel per pixel): 24x32 tile, 12+4 waves, one per CU; the
+  //   tile is narrow along U so that a window row (tile + drift + pair) fits a 32-unit LDS pitch
+  // (one loader wave moves ~10 B/cycle at best, MI355X_MICROARCH.md 'ldsdma-fill'; a heavy
+  //  stream needs several per CU)
   struct Cfg { int tw, th, nl; };
-  Cfg cfgs[2] = {{32, 16, 1}, {32, 24, 4}};
+  Cfg cfgs[2] = {{32, 16, 1}, {24, 32, 4}};
   int ncfg = 2;
   if (opt_tile == 1) { cfgs[0] = {16, 16, 1}; ncfg = 1; }
-  else if (opt_tile == 2) { cfgs[0] = {32, 24, 4}; ncfg = 1; }
+  else if (opt_tile == 2) { cfgs[0] = {24, 32, 4}; ncfg = 1; }
   else if (opt_tile == 3) { cfgs[0] = {24, 16, 2}; ncfg = 1; }
-  else if (opt_tile == 4) { cfgs[0] = {64, 8, 1}; ncfg = 1; }
+  else if (opt_tile == 4) { cfgs[0] = {32, 24, 4}; ncfg = 1; }
   else if (opt_tile == 5) { cfgs[0] = {32, 16, 2}; ncfg = 1; }
   else if (opt_tile == 6) { cfgs[0] = {32, 16, 1}; ncfg = 1; }
+  else if (opt_tile == 7) { cfgs[0] = {16, 32, 2}; ncfg = 1; }
   else if (opt_tile == 8) { cfgs[0] = {32, 16, 4}; ncfg = 1; }
+  else if (opt_tile == 9) { cfgs[0] = {16, 32, 1}; ncfg = 1; }
+  else if (opt_tile == 10) { cfgs[0] = {24, 32, 2}; ncfg = 1; }
+  else if (opt_tile == 11) { cfgs[0] = {24, 24, 2}; ncfg = 1; }
   const int upv = dtype == 0 ? 2 : 1;
-  const size_t vb = dtype == 0 ? 8 : 16;
   for (int ci = 0; ci < ncfg; ++ci) {
     const int tw = cfgs[ci].tw, th = cfgs[ci].th, nl = cfgs[ci].nl;
     const int nw = (tw / 8) * (th / 8);
@@ -675,14 +866,33 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     // two-slice interval a window covers + texel pair + eps
     double max_eu = 0, max_ev = 0, max_drift_u = 0, max_drift_v = 0;
     const double sf[2] = {-0.5, (double)P.N[as] - 0.5};
+    std::vector<int> work((size_t)P.ntx * P.nty, 1);  // slices each tile streams (schedule weight)
     for (int tyi = 0; tyi < P.nty; ++tyi)
       for (int txi = 0; txi < P.ntx; ++txi) {
         double umin[2] = {1e300, 1e300}, umax[2] = {-1e300, -1e300}, vmin[2] = {1e300, 1e300}, vmax[2] = {-1e300, -1e300};
+        double smin_t = 1e300, smax_t = -1e300;
         for (int c = 0; c < 4; ++c) {
           int cx = std::min(txi * tw + ((c & 1) ? tw - 1 : 0), P.W - 1);
           int cy = std::min(tyi * th + ((c & 2) ? th - 1 : 0), P.H - 1);
           double A[3], B[3];
           host_ray(P, cx, cy, A, B);
+          {  // the ray's stretch inside the region, as slices along S
+            double t0 = 0, t1 = P.rc.nplanes - 1;
+            bool miss = false;
+            for (int a = 0; a < 3; ++a) {
+              if (fabs(B[a]) > 1e-20) {
+                double ta = (P.lo[a] - A[a]) / B[a], tb = (P.hi[a] - A[a]) / B[a];
+                t0 = std::max(t0, std::min(ta, tb));
+                t1 = std::min(t1, std::max(ta, tb));
+              } else if (!(A[a] >= P.lo[a] && A[a] <= P.hi[a]))
+                miss = true;
+            }
+            if (!miss && t0 <= t1) {
+              double sa = A[as] + t0 * B[as], sb = A[as] + t1 * B[as];
+              smin_t = std::min(smin_t, std::min(sa, sb));
+              smax_t = std::max(smax_t, std::max(sa, sb));
+            }
+          }
           if (!(B[as] * Q.dir > 0) || fabs(B[as]) < 1e-12) { *why = "rays do not share a marching direction"; return hipErrorNotSupported; }
           double du = fabs(B[Q.au] / B[as]), dv = fabs(B[Q.av] / B[as]);
           if (du > 1.5 || dv > 1.5) { *why = "view too oblique for the principal axis"; return hipErrorNotSupported; }
@@ -699,45 +909,122 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
           max_eu = std::max(max_eu, umax[f] - umin[f]);
           max_ev = std::max(max_ev, vmax[f] - vmin[f]);
         }
+        if (smin_t <= smax_t) work[(size_t)tyi * P.ntx + txi] = 16 + (int)(smax_t - smin_t);
       }
     // a window spans s in [j-1, j+1] (2 slices of drift; 2.5 at the faces), + pair + eps + rounding
     int Wu = (int)ceil(max_eu + 2.5 * max_drift_u + 2 * SLAB_EPS) + 3;
     int Wv = (int)ceil(max_ev + 2.5 * max_drift_v + 2 * SLAB_EPS) + 3;
-    if (dtype == 0) Wu += 2;  // even alignment of both ends
+    if (dtype == 0) Wu = ((Wu + 1) & ~1) + 2;  // even width, even alignment of the origin
     Wu = std::min(Wu, Q.Du);
     Wv = std::min(Wv, Q.Dv);
     if (Wu < 2 || Wv < 2) { *why = "degenerate window"; return hipErrorNotSupported; }
-    if (Wu > 255 || Wv > 255) { *why = "window too large"; return hipErrorNotSupported; }
-    Q.slot_vox = ((Wu * Wv + 64 * upv - 1) / (64 * upv)) * (64 * upv);
-    Q.chunks = Q.slot_vox / (64 * upv);
-    if (Q.chunks > 63) { *why = "window needs more than 63 DMA chunks"; return hipErrorNotSupported; }
+    // fixed window shape: wu 16-byte units per row on an LDS pitch of the next power of two (so a
+    // DMA chunk is 64 >> wp_log2 WHOLE rows and a lane's offset in the window is a constant)
+    Q.wu = Wu / upv;
+    Q.wv = Wv;
+    if (Q.wu > 64) { if (ci + 1 < ncfg) continue; *why = "window wider than one DMA chunk"; return hipErrorNotSupported; }
+    Q.wp_log2 = 0;
+    while ((1 << Q.wp_log2) < Q.wu) ++Q.wp_log2;
+    const int rpc = 64 >> Q.wp_log2;
+    Q.chunks = (Q.wv + rpc - 1) / rpc;
+    Q.slot_bytes = Q.chunks * 1024;
+    if (Q.chunks > 63) { if (ci + 1 < ncfg) continue; *why = "window needs more than 63 DMA chunks"; return hipErrorNotSupported; }
     // light enough for this configuration?  otherwise try the next (heavier-duty) one
     if (ci + 1 < ncfg && (double)Q.chunks * 1024.0 / (nw * 64) > 16.0 * nl) continue;
 
-    Q.use_ah = (P.third_axis && P.nelts <= 3 && P.sv <= 2048) ? 1 : 0;
-    Q.gmax = std::min(opt_T > 0 ? opt_T : 3, 3);  // <= 3: a consumer step caches 4 slice windows
-    const size_t fixed = (size_t)Q.Ds * sizeof(SlabWin) + (8 + 32) * 4 + 64 + (Q.use_ah ? (size_t)P.sv * 4 : 0);
+    Q.use_ah = (P.third_axis && P.nelts <= 3 && P.sv >= 2 && P.sv <= 2048) ? 1 : 0;
+    if (P.sv < 2 || P.sg < 2) { *why = "transfer function smaller than 2x2"; return hipErrorNotSupported; }
+    const size_t fixed = (size_t)Q.Ds * sizeof(SlabEnt) + (8 + 32) * 4 + 64 + (Q.use_ah ? (size_t)P.sv * 4 : 0);
     // ring: as many slots as fit two workgroups per CU (small tiles) or one (big tiles)
-    size_t budget = (nw + nl) * 64 > 640 ? 158 * 1024 : 78 * 1024;
-    int ns = (int)((budget - fixed) / ((size_t)Q.slot_vox * vb));
-    if (ns > 16) ns = 16;
-    if (ns < 4) {
-      ns = (int)((158 * 1024 - fixed) / ((size_t)Q.slot_vox * vb));
-      if (ns > 8) ns = 8;
+    size_t budget = (nw + nl) * 64 > 640 ? 158 * 1024 : (P.wave_w == 4 ? 52 * 1024 : 78 * 1024);  // (wave_w: experiment knob)
+    if (budget <= fixed) { *why = "slice table does not fit LDS"; return hipErrorNotSupported; }
+    int ns = (int)((budget - fixed) / (size_t)Q.slot_bytes);
+    if (ns > 24) ns = 24;
+    // a wave holds ceil(slices per plane) + 1 slices while it works and the loaders want a few in flight
+    const int band = (int)ceil(fabs(Bc[as])) + 2;
+    if (ns < band + 2 && 158 * 1024 > fixed) {
+      ns = (int)((158 * 1024 - fixed) / (size_t)Q.slot_bytes);
+      if (ns > band + 4) ns = band + 4;
     }
-    if (ns < 4) { *why = "window does not fit LDS"; return hipErrorNotSupported; }
+    if (ns < 3) { if (ci + 1 < ncfg) continue; *why = "window does not fit LDS"; return hipErrorNotSupported; }
     Q.nslots = ns;
-    if (Q.gmax > ns - 2) Q.gmax = ns - 2;
     const int mych = (Q.chunks + nl - 1) / nl;  // most DMA instructions one loader issues per slice
-    Q.maxfly = std::min(ns - 2, 63 / mych + 1);
-    if (Q.maxfly < 1) Q.maxfly = 1;
-    if (P.wave_w != 8) Q.maxfly = std::max(1, std::min(P.wave_w, Q.maxfly));  // (experiment knob)
-    const size_t lds = (size_t)ns * Q.slot_vox * vb + fixed;
-#define GO(D, S, R, N, L) \
-  if (dtype == D && shade_kind == S && Q.perm == R && nw == N && nl == L) return launch_slab<D, S, R, N, L>(P, Q, lds, s);
-#define GO_NW(D, S, R) GO(D, S, R, 4, 1) GO(D, S, R, 6, 2) GO(D, S, R, 8, 1) GO(D, S, R, 8, 2) GO(D, S, R, 8, 4) GO(D, S, R, 12, 4)
+    Q.maxfly = std::max(1, std::min(ns, 63 / mych + 1));
+    Q.kband = opt_T > 0 ? opt_T : 1 << 20;  // (experiment knob)
+    const size_t lds = (size_t)ns * Q.slot_bytes + fixed;
+    // ---- schedule.  Blocks are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8, in
+    // order of b), each XCD with its own L2.  Every XCD gets one contiguous run of image tiles
+    // (row-major: neighbours that walk neighbouring voxels share an L2) cut so that all runs
+    // stream about the same number of slices -- tiles at the image border cross less of the
+    // volume than central ones -- and starts its long tiles first (shortest tail).
+    int nblocks = 0;
+    {
+      const int nt = P.ntx * P.nty;
+      long long total = 0;
+      for (int t = 0; t < nt; ++t) total += work[t];
+      std::vector<std::vector<int>> run(8);
+      long long acc = 0;
+      for (int t = 0; t < nt; ++t) {
+        int x = (int)std::min<long long>(7, (acc + work[t] / 2) * 8 / std::max<long long>(total, 1));
+        run[x].push_back(t);
+        acc += work[t];
+      }
+      size_t longest = 0;
+      for (int x = 0; x < 8; ++x) {
+        std::stable_sort(run[x].begin(), run[x].end(), [&](int a, int b) { return work[a] > work[b]; });
+        longest = std::max(longest, run[x].size());
+      }
+      nblocks = (int)longest * 8;
+      std::vector<int> order((size_t)nblocks, -1);
+      for (int x = 0; x < 8; ++x)
+        for (size_t k = 0; k < run[x].size(); ++k) order[k * 8 + x] = run[x][k];
+      if (aux->order_host != order) {  // unchanged camera: the table on the device is still right
+        if ((int)order.size() > aux->order_cap) {
+          if (aux->d_order) (void)hipFree(aux->d_order);
+          aux->d_order = nullptr;
+          aux->order_cap = 0;
+          hipError_t e = hipMalloc((void **)&aux->d_order, order.size() * sizeof(int));
+          if (e != hipSuccess) return e;
+          aux->order_cap = (int)order.size();
+        }
+        hipError_t e = hipMemcpyAsync(aux->d_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return e;
+        aux->order_host.swap(order);
+      }
+      Q.order = aux->d_order;
+      Q.trace = nullptr;
+      if (P.lockstep & 32) {
+        if (nblocks > aux->trace_cap) {
+          if (aux->d_trace) (void)hipFree(aux->d_trace);
+          aux->d_trace = nullptr;
+          aux->trace_cap = 0;
+          hipError_t e = hipMalloc((void **)&aux->d_trace, (size_t)nblocks * 16);
+          if (e != hipSuccess) return e;
+          aux->trace_cap = nblocks;
+        }
+        hipError_t e = hipMemsetAsync(aux->d_trace, 0, (size_t)nblocks * 16, s);
+        if (e != hipSuccess) return e;
+        aux->trace_n = nblocks;
+        Q.trace = aux->d_trace;
+      }
+    }
+    // developer diagnostics (option lockstep bits 2..64) live in separate instances of the f32 +
+    // R8k kernels only: compiled into the product kernels they cost SGPRs (spills) in every frame
+    const bool diag = (P.lockstep & ~1) != 0 && dtype == 1 && shade_kind == 1;
+#define GO(D, S, R, N, L)                                                                              \
+  if (dtype == D && shade_kind == S && Q.perm == R && nw == N && nl == L) {                          \
+    if constexpr (D == 1 && S == 1) {                                                                \
+      if (diag) return launch_slab<D, S, R, N, L, true>(P, Q, lds, nblocks, s);                      \
+    }                                                                                                \
+    return launch_slab<D, S, R, N, L, false>(P, Q, lds, nblocks, s);                                 \
+  }
+#define GO_NW(D, S, R) GO(D, S, R, 4, 1) GO(D, S, R, 6, 2) GO(D, S, R, 8, 1) GO(D, S, R, 8, 2) GO(D, S, R, 8, 4) GO(D, S, R, 9, 2) GO(D, S, R, 12, 2) GO(D, S, R, 12, 4)
 #define GO_R(D, S) GO_NW(D, S, 0) GO_NW(D, S, 1) GO_NW(D, S, 2)
+#ifdef SLAB_FEW_INSTANCES
+    GO_R(1, 1)
+#else
     GO_R(0, 0) GO_R(0, 1) GO_R(0, 2) GO_R(1, 0) GO_R(1, 1) GO_R(1, 2)
+#endif
 #undef GO_R
 #undef GO_NW
 #undef GO

@@ -41,14 +41,33 @@ def test_every_axis_and_direction(R, pose, f32):
 
 
 @pytest.mark.parametrize("kind,shade", [("cfg2", 0), ("cfg3", 1), ("cfg3", 2), ("cfg4", 0)])
-def test_modes_and_depth(R, kind, shade):
+def test_modes(R, kind, shade):
     sc = make_scene(kind, n=32, size=64, steps=64, pose="diag", f32=True, shade=shade)
-    (ref, rd) = sc.render(depth=True)
-    (a, ad), (b, bd) = _both(R, sc, depth=True)
-    assert np.array_equal(a, b) and np.array_equal(ad, bd)
+    ref = sc.render()
+    a, b = _both(R, sc)
+    assert np.array_equal(a, b)
     assert np.abs(b - ref).max() <= TOL
+
+
+def test_depth_request_uses_the_gather_kernel(R):
+    """First-hit depth is a register the slice-ring kernel does not spend: a frame that asks for
+    it runs on the gather kernel in auto mode (same RGBA, bit for bit) and is refused when the
+    slice-ring kernel is forced."""
+    sc = make_scene("cfg3", n=32, size=64, steps=64, pose="diag", f32=True, shade=1)
+    (ref, rd) = sc.render(depth=True)
+    push_scene(R, sc)
+    R.set_option("kernel", 0)
+    rgba, dep = R.render(depth=True)
+    assert R.last_frame_info()[0] == 1
+    plain = R.render()
+    assert R.last_frame_info()[0] == 2
+    assert np.array_equal(rgba, plain)
     fin = np.isfinite(rd)
-    assert np.array_equal(fin, np.isfinite(bd)) and np.abs(rd[fin] - bd[fin]).max() <= 1e-4
+    assert np.array_equal(fin, np.isfinite(dep)) and np.abs(rd[fin] - dep[fin]).max() <= 1e-4
+    R.set_option("kernel", 2)
+    with pytest.raises(Exception, match="depth"):
+        R.render(depth=True)
+    R.set_option("kernel", 0)
 
 
 @pytest.mark.parametrize("pose", ["z-", "y+", "x-"])

@@ -63,10 +63,44 @@ def main():
         print("%-32s kernel=%d  %.3f ms/frame  (event avg %.3f ms)  %.1f GB/s alg  frac %.3f  maxdiff_vs_first %.2e  alpha_mean %.4f"
               % (var, kern, t / a.frames * 1e3, kms, alg / (kms * 1e-3) / 1e9, alg / (kms * 1e-3) / 1e9 / 8000, err, img[:, 3].mean()),
               flush=True)
-        if "lockstep=6" in var or "lockstep=4" in var:
-            t = img[::-1][:1024]
-            t = t[t[:, 3] > 0]
-            print("   loader cycles (mean over %d WGs): issue %.0f  wait %.0f  idle %.0f  total %.0f" % ((len(t),) + tuple(t.mean(0))))
+        if any(kv.split("=")[0] == "lockstep" and int(kv.split("=")[1]) & 16 for kv in var.split(",")):
+            it, act, ins, hit = (r.stat(k) for k in ("slab_iters", "slab_active_lanes", "slab_inside_lanes", "slab_hit_lanes"))
+            print("   consumer wave-iterations %.4g: lanes active %.1f%%, inside %.1f%%, hit %.1f%% of 64; iterations with a hit %.1f%%" %
+                  (it, 100 * act / (64 * it + 1e-9), 100 * ins / (64 * it + 1e-9), 100 * hit / (64 * it + 1e-9),
+                   100 * r.stat("slab_iters_with_hit") / (it + 1e-9)), flush=True)
+            li, lw, lb, lt = (r.stat(k) for k in ("slab_loader_issue_kcyc", "slab_loader_wait_kcyc", "slab_loader_blocked_kcyc", "slab_loader_total_kcyc"))
+            print("   loader 0 of every workgroup, sum of kilo-cycles: issue(+poll) %.4g  vmcnt wait %.4g  ring-blocked %.4g  total %.4g  (= %.3f ms per CU at 2.4 GHz if spread over 256 CUs)" %
+                  (li, lw, lb, lt, lt * 1e3 / 256 / 2.4e9 * 1e3), flush=True)
+        if any(kv.split("=")[0] == "lockstep" and int(kv.split("=")[1]) & 32 for kv in var.split(",")):
+            tr = r.trace()
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            np.save(os.path.join(ROOT, 'gpurun_out', 'trace_%s.npy' % var.replace(',', '_').replace('=', '')), tr)
+            tr = tr[tr[:, 1] != 0]
+            t0 = tr[:, 0].astype(np.int64)
+            t1 = tr[:, 1].astype(np.int64)
+            base_t = t0.min()
+            dur = (t1 - t0) / 100.0  # us
+            cu = (tr[:, 2] >> 8) & 0xf
+            se = (tr[:, 2] >> 13) & 0x7
+            sh = (tr[:, 2] >> 12) & 1
+            xcc = tr[:, 3] & 0xf
+            key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+            print("   trace: %d workgroups on %d distinct (xcc,se,sh,cu); frame span %.1f us; WG duration min/mean/max %.1f/%.1f/%.1f us"
+                  % (len(tr), len(np.unique(key)), (t1.max() - base_t) / 100.0, dur.min(), dur.mean(), dur.max()))
+            busy = {}
+            last = {}
+            for k_, a_, b_ in zip(key, t0, t1):
+                busy[k_] = busy.get(k_, 0) + (b_ - a_)
+                last[k_] = max(last.get(k_, 0), b_)
+            bz = np.array(list(busy.values())) / 100.0
+            ends = (np.array(list(last.values())) - base_t) / 100.0
+            print("   per-CU busy us min/mean/max %.1f/%.1f/%.1f ; last-end us min/mean/max %.1f/%.1f/%.1f" %
+                  (bz.min(), bz.mean(), bz.max(), ends.min(), ends.mean(), ends.max()))
+            for x in range(8):
+                m = xcc == x
+                if m.any():
+                    print("   xcc %d: %4d WGs, sum busy %.0f us, first start %.1f last end %.1f, slices %d" %
+                          (x, m.sum(), dur[m].sum(), (t0[m].min() - base_t) / 100.0, (t1[m].max() - base_t) / 100.0, int((tr[m, 3] >> 20).sum())))
     r.close()
 
 
