@@ -291,7 +291,7 @@ class Renderer:
     def trace(self):
         n = C.c_int(0)
         self._ck(self.L.smk_get_trace(self.ctx, None, 0, C.byref(n)))
-        out = np.zeros((max(n.value, 0), 4), dtype=np.uint32)
+        out = np.zeros((max(n.value, 0), 8), dtype=np.uint32)
         if n.value > 0:
             self._ck(self.L.smk_get_trace(self.ctx, out.ctypes.data, n.value, C.byref(n)))
         return out

@@ -83,6 +83,8 @@ extern "C" void smk_destroy(smk_ctx *c) {
   if (c->slab.h_status) (void)hipHostFree(c->slab.h_status);
   if (c->slab.d_diag) (void)hipFree(c->slab.d_diag);
   if (c->slab.d_order) (void)hipFree(c->slab.d_order);
+  if (c->slab.h_order) (void)hipHostFree(c->slab.h_order);
+  if (c->slab.order_ev) (void)hipEventDestroy(c->slab.order_ev);
   if (c->slab.d_trace) (void)hipFree(c->slab.d_trace);
   for (hipEvent_t e : c->tev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->tev1) (void)hipEventDestroy(e);
@@ -657,10 +659,10 @@ static int check_slab_status(smk_ctx *c) {
 extern "C" int smk_get_stat(smk_ctx *c, const char *name, double *value) {
   if (!c || !name || !value) return 1;
   HIPCHK(c, hipSetDevice(c->device));
-  static const char *diag_names[9] = {"slab_iters", "slab_active_lanes", "slab_inside_lanes", "slab_hit_lanes",
+  static const char *diag_names[12] = {"slab_iters", "slab_active_lanes", "slab_inside_lanes", "slab_hit_lanes",
                                       "slab_loader_issue_kcyc", "slab_loader_wait_kcyc", "slab_loader_blocked_kcyc", "slab_loader_total_kcyc",
-                                      "slab_iters_with_hit"};
-  for (int k = 0; k < 9; ++k)
+                                      "slab_iters_with_hit", "slab_lead_sum", "slab_waits", "slab_wstep_sum"};
+  for (int k = 0; k < 12; ++k)
     if (!strcmp(name, diag_names[k])) {
       float v = 0.f;
       if (c->slab.d_diag) {
@@ -684,7 +686,7 @@ extern "C" int smk_get_trace(smk_ctx *c, unsigned *out, int cap_records, int *nr
   *nrecords = c->slab.d_trace ? c->slab.trace_n : 0;
   if (out && *nrecords > 0) {
     HIPCHK(c, hipDeviceSynchronize());
-    HIPCHK(c, hipMemcpy(out, c->slab.d_trace, (size_t)std::min(cap_records, *nrecords) * 16, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out, c->slab.d_trace, (size_t)std::min(cap_records, *nrecords) * 32, hipMemcpyDeviceToHost));
   }
   return 0;
 }

@@ -62,6 +62,8 @@ struct SlabAux {
   int *h_status = nullptr;      // pinned, device-visible: error word (0 = ok)
   float *d_diag = nullptr;      // [16] diagnostic counters (option lockstep bit 16)
   int *d_order = nullptr;       // tile schedule of the current camera
+  int *h_order = nullptr;       // its pinned staging copy
+  hipEvent_t order_ev = nullptr;  // completion of the last staging -> device copy
   int order_cap = 0;
   std::vector<int> order_host;  // what d_order holds
   unsigned *d_trace = nullptr;  // [trace_n][4] workgroup timeline of the last traced frame (option lockstep bit 32)

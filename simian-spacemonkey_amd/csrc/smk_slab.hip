@@ -28,6 +28,8 @@
 // (same fma chains), so the two kernels and the CPU checker agree bit for bit on positions.
 // Reference semantics: see smk_device.h.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -49,7 +51,8 @@ struct SlabParams {
   int slot_bytes;              // chunks * 1024
   int nslots;                  // ring size
   int maxfly;                  // slices a loader keeps in flight ((maxfly-1) * its chunks <= 63)
-  int kband;                   // a lane may run at most this many positions ahead of its wave's slowest lane
+  int wstep;                   // a wave steps when slices up to its slowest lane's position + 1 + wstep have landed
+  int pmask;                   // consumers publish progress when (iteration & pmask) == 0
   int dir;                     // +1: rays advance towards +S, -1: towards -S
   int tw, th;                  // pixel tile
   const void *vox;             // layout base (native or x-major)
@@ -57,7 +60,7 @@ struct SlabParams {
   const int *order;            // tile of each block (work-balanced schedule, -1 = none), see smk_launch_slab
   int *status;                 // host-visible word: 1 = protocol time-out, 2 = window bound violated
   float *diag;                 // [16] diagnostic counters (lockstep bit 16) or null
-  unsigned *trace;             // [nblocks][4] per-workgroup {start, end (100 MHz ticks), HW_ID, XCC_ID} (lockstep bit 32) or null
+  unsigned *trace;             // [nblocks][8] per-workgroup timeline record (lockstep bit 32, see smk.h) or null
 };
 
 #define SLAB_EPS 0.02f
@@ -462,7 +465,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       // table entries of 64 consecutive load indices, one per lane, refreshed every 64 slices:
       // a slice's window origin is then one v_readlane away instead of an LDS round trip
       int ent_uv = 0;
-      const bool prof = DIAG && (P.lockstep & 16) != 0 && Q.diag != nullptr;  // (diagnostic: where a loader's cycles go)
+      const bool prof = DIAG && (P.lockstep & 48) != 0 && Q.diag != nullptr;  // (diagnostic: where a loader's cycles go)
       long long t_issue = 0, t_wait = 0, t_idle = 0, t_mark = 0;
       const long long t_start = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
       while (landed <= npos) {
@@ -549,6 +552,12 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       }
 #undef SLAB_DMA
       wait_vmcnt(0);
+      if (tracing && lane == 0 && lid == 0) {
+        unsigned *t = Q.trace + 8 * (size_t)blockIdx.x;
+        t[4] = (unsigned)(t_issue >> 6);
+        t[5] = (unsigned)(t_wait >> 6);
+        t[6] = (unsigned)(t_idle >> 6);
+      }
       if (prof && lane == 0 && lid == 0) {
         atomicAdd(&Q.diag[4], (float)t_issue * 1e-3f);
         atomicAdd(&Q.diag[5], (float)t_wait * 1e-3f);
@@ -571,8 +580,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       };
       const bool stream_only = DIAG && (P.lockstep & 2) != 0;  // (diagnostic: consume nothing)
       if (DIAG && (P.lockstep & 64)) pb = SLAB_DONE;   // (diagnostic: free-running stream)
-      const bool count = DIAG && (P.lockstep & 16) != 0 && Q.diag != nullptr;
-      float n_it = 0.f, n_act = 0.f, n_in = 0.f, n_hit = 0.f, n_anyhit = 0.f;
+      const bool count = DIAG && (P.lockstep & 48) != 0 && Q.diag != nullptr;
+      float n_it = 0.f, n_act = 0.f, n_in = 0.f, n_hit = 0.f, n_anyhit = 0.f, n_lead = 0.f, n_waits = 0.f, n_wstep = 0.f;
       int have = 0;  // cached copy of `landed` (monotonic): re-polled only when a lane is blocked on it
       // table row of the sample's base slice: entry index = bs - Os = psgn*pb + (-psgn*poff - Os)
       const int eoff = -psgn * poff - Q.Os;
@@ -581,32 +590,33 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       for (int it = 0;; ++it) {
         const bool want = pb < SLAB_DONE;
         if (!__any(want)) break;  // every ray of this wave is finished
-        // progress = position of the slowest lane, published every other iteration (the DPP
-        // reduction is ~12 VALU; a stale value only delays slot recycling by one step)
-#ifndef SLAB_PROGRESS_MASK
-#define SLAB_PROGRESS_MASK 1
-#endif
-        if (!(it & SLAB_PROGRESS_MASK)) {
+        // progress = position of the slowest lane (DPP reduction, ~12 VALU), published every
+        // iteration on a short ring and every other one where a stale value only delays slot
+        // recycling by a step
+        if (!(it & Q.pmask)) {
           const int plo = wave_min_i32(pb);
           if (plo != pos) {  // positions below plo are done: their lower slices may be recycled
             pos = plo;       // (every slot read of earlier iterations has returned: slab_read8 waits)
             if (lane == 0) lds_st(&ctl[8 + wave], pos);
           }
         }
-        // (kband: the slices between the wave's slowest and fastest lane stay resident, so a
-        //  narrow band leaves more of a small ring to the loaders at the price of idle lanes)
-        const int ptop = pos + Q.kband;
-        bool act = want && pb + 2 <= have && pb <= ptop;
-        if (__any(want && pb <= ptop && !act)) {
+        // Take a step only when the whole band of this wave can: lanes sit up to one sample
+        // spacing (wstep slices) ahead of the slowest one, and an iteration costs the wave the
+        // same issue slots whether 5 or 64 lanes take part.  Stepping the moment ONE lane's slices
+        // have landed was measured at up to 2.3x the iterations per ray on a starved stream.
+        int need = min(pos + 2 + Q.wstep, npos + 1);
+        if (have < need) {
           have = landed_all();
-          if (!__any(want && pb + 2 <= have && pb <= ptop)) {
-            // nobody can move: make sure `pos` is this wave's true minimum, then wait for its slices
+          if (have < need) {
+            // make sure `pos` is this wave's true minimum before sleeping on it
             const int plo = wave_min_i32(pb);
             if (plo != pos) {
               pos = plo;
               if (lane == 0) lds_st(&ctl[8 + wave], pos);
+              need = min(pos + 2 + Q.wstep, npos + 1);
             }
-            for (int spins = 0; have < pos + 2; ++spins) {
+            if (count) n_waits += 1.f;
+            for (int spins = 0; have < need; ++spins) {
               if (spins > (1 << 22) || lds_ld(&ctl[3])) {  // bounded: never hang the GPU on a protocol bug
                 lds_st(&ctl[3], 1);
                 have = 0x3ffffff0;
@@ -621,7 +631,11 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             }
           }
           have = __builtin_amdgcn_readfirstlane(have);
-          act = pb < SLAB_DONE && pb + 2 <= have && pb <= pos + Q.kband;
+        }
+        const bool act = pb < SLAB_DONE && pb + 2 <= have;
+        if (count) {
+          n_lead += (float)(have - pos);
+          n_wstep += (float)Q.wstep;
         }
         asm volatile("" ::: "memory");  // slot reads stay behind the poll
         bool d_hit = false;  // (diagnostic counters only)
@@ -745,12 +759,16 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
         }
       }
       if (lane == 0) lds_st(&ctl[8 + wave], SLAB_DONE);
+      if (tracing && lane == 0) atomicAdd(Q.trace + 8 * (size_t)blockIdx.x + 7, (unsigned)n_it);
       if (count && lane == 0) {
         atomicAdd(&Q.diag[0], n_it);
         atomicAdd(&Q.diag[1], n_act);
         atomicAdd(&Q.diag[2], n_in);
         atomicAdd(&Q.diag[3], n_hit);
         atomicAdd(&Q.diag[8], n_anyhit);
+        atomicAdd(&Q.diag[9], n_lead);
+        atomicAdd(&Q.diag[10], n_waits);
+        atomicAdd(&Q.diag[11], n_wstep);
       }
     }
   }
@@ -764,7 +782,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
     if (tid == 0 && ctl[3]) *(volatile int *)Q.status = ctl[3];
   }
   if (tracing && tid == 0) {
-    unsigned *t = Q.trace + 4 * (size_t)blockIdx.x;
+    unsigned *t = Q.trace + 8 * (size_t)blockIdx.x;
     t[0] = trace_t0;
     t[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
     t[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
@@ -839,7 +857,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
   // (one loader wave moves ~10 B/cycle at best, MI355X_MICROARCH.md 'ldsdma-fill'; a heavy
   //  stream needs several per CU)
   struct Cfg { int tw, th, nl; };
-  Cfg cfgs[2] = {{32, 16, 1}, {24, 32, 4}};
+  Cfg cfgs[2] = {{32, 16, 1}, {32, 24, 4}};
   int ncfg = 2;
   if (opt_tile == 1) { cfgs[0] = {16, 16, 1}; ncfg = 1; }
   else if (opt_tile == 2) { cfgs[0] = {24, 32, 4}; ncfg = 1; }
@@ -865,16 +883,15 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     // bundle cross-section extent (corner rays of every tile) at the two S faces + drift over the
     // two-slice interval a window covers + texel pair + eps
     double max_eu = 0, max_ev = 0, max_drift_u = 0, max_drift_v = 0;
-    const double sf[2] = {-0.5, (double)P.N[as] - 0.5};
     std::vector<int> work((size_t)P.ntx * P.nty, 1);  // slices each tile streams (schedule weight)
     for (int tyi = 0; tyi < P.nty; ++tyi)
       for (int txi = 0; txi < P.ntx; ++txi) {
-        double umin[2] = {1e300, 1e300}, umax[2] = {-1e300, -1e300}, vmin[2] = {1e300, 1e300}, vmax[2] = {-1e300, -1e300};
+        double cA[4][3], cB[4][3];
         double smin_t = 1e300, smax_t = -1e300;
         for (int c = 0; c < 4; ++c) {
           int cx = std::min(txi * tw + ((c & 1) ? tw - 1 : 0), P.W - 1);
           int cy = std::min(tyi * th + ((c & 2) ? th - 1 : 0), P.H - 1);
-          double A[3], B[3];
+          double *A = cA[c], *B = cB[c];
           host_ray(P, cx, cy, A, B);
           {  // the ray's stretch inside the region, as slices along S
             double t0 = 0, t1 = P.rc.nplanes - 1;
@@ -898,22 +915,33 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
           if (du > 1.5 || dv > 1.5) { *why = "view too oblique for the principal axis"; return hipErrorNotSupported; }
           max_drift_u = std::max(max_drift_u, du);
           max_drift_v = std::max(max_drift_v, dv);
-          for (int f = 0; f < 2; ++f) {
-            double mm = (sf[f] - A[as]) / B[as];
-            double u = A[Q.au] + B[Q.au] * mm, v = A[Q.av] + B[Q.av] * mm;
-            umin[f] = std::min(umin[f], u); umax[f] = std::max(umax[f], u);
-            vmin[f] = std::min(vmin[f], v); vmax[f] = std::max(vmax[f], v);
-          }
         }
+        if (!(smin_t <= smax_t)) continue;  // no corner ray meets the region: (almost) nothing to stream
+        work[(size_t)tyi * P.ntx + txi] = 16 + (int)(smax_t - smin_t);
+        // cross-section of the bundle where THIS tile streams: it is linear in s (perspective), so
+        // the two ends of the tile's own slice range bound it.  The range is padded: an interior
+        // ray may enter up to a tile's drift earlier than every corner ray (a cube edge or vertex
+        // facing the eye), and windows reach one slice beyond the slices they serve.  (Bounding by
+        // the volume's S faces instead costs 25-30 % window area at a voxel per pixel: rays are not
+        // inside the volume where they are widest apart.)
+        const double pad = 4.0 + 3.0 * fabs(Bc[as]) + 0.5 * std::max(tw, th) * std::max(max_drift_u, max_drift_v);
+        const double se[2] = {std::max(-0.5, smin_t - pad), std::min((double)P.N[as] - 0.5, smax_t + pad)};
         for (int f = 0; f < 2; ++f) {
-          max_eu = std::max(max_eu, umax[f] - umin[f]);
-          max_ev = std::max(max_ev, vmax[f] - vmin[f]);
+          double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
+          for (int c = 0; c < 4; ++c) {
+            double mm = (se[f] - cA[c][as]) / cB[c][as];
+            double u = cA[c][Q.au] + cB[c][Q.au] * mm, v = cA[c][Q.av] + cB[c][Q.av] * mm;
+            umin = std::min(umin, u); umax = std::max(umax, u);
+            vmin = std::min(vmin, v); vmax = std::max(vmax, v);
+          }
+          max_eu = std::max(max_eu, umax - umin);
+          max_ev = std::max(max_ev, vmax - vmin);
         }
-        if (smin_t <= smax_t) work[(size_t)tyi * P.ntx + txi] = 16 + (int)(smax_t - smin_t);
       }
-    // a window spans s in [j-1, j+1] (2 slices of drift; 2.5 at the faces), + pair + eps + rounding
-    int Wu = (int)ceil(max_eu + 2.5 * max_drift_u + 2 * SLAB_EPS) + 3;
-    int Wv = (int)ceil(max_ev + 2.5 * max_drift_v + 2 * SLAB_EPS) + 3;
+    // a window spans s in [j-1, j+1] (2 slices of drift; 2.5 at the faces); a coordinate range of
+    // extent e touches at most ceil(e) + 2 texels (pair included); eps for the fp32 chains
+    int Wu = (int)ceil(max_eu + 2.5 * max_drift_u + 2 * SLAB_EPS) + 2;
+    int Wv = (int)ceil(max_ev + 2.5 * max_drift_v + 2 * SLAB_EPS) + 2;
     if (dtype == 0) Wu = ((Wu + 1) & ~1) + 2;  // even width, even alignment of the origin
     Wu = std::min(Wu, Q.Du);
     Wv = std::min(Wv, Q.Dv);
@@ -950,8 +978,13 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     Q.nslots = ns;
     const int mych = (Q.chunks + nl - 1) / nl;  // most DMA instructions one loader issues per slice
     Q.maxfly = std::max(1, std::min(ns, 63 / mych + 1));
-    Q.kband = opt_T > 0 ? opt_T : 1 << 20;  // (experiment knob)
+    Q.wstep = std::max(0, std::min((int)ceil(fabs(Bc[as])), ns - 3));
+    if (opt_T > 0) Q.wstep = std::max(0, std::min(opt_T - 1, ns - 3));  // (experiment knob: slab_T = wstep + 1)
+    Q.pmask = ns >= 2 * band ? 1 : 0;
     const size_t lds = (size_t)ns * Q.slot_bytes + fixed;
+    if (getenv("SMK_DEBUG"))
+      fprintf(stderr, "[smk] slice-ring plan: tile %dx%d, %d+%d waves, window %d units x %d rows (pitch %d), %d chunks/slice, %d slots of %d B, table+ctl %zu B, LDS %zu B, band %d, wstep %d, pmask %d, maxfly %d\n",
+              tw, th, nw, nl, Q.wu, Q.wv, 1 << Q.wp_log2, Q.chunks, ns, Q.slot_bytes, fixed, lds, band, Q.wstep, Q.pmask, Q.maxfly);
     // ---- schedule.  Blocks are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8, in
     // order of b), each XCD with its own L2.  Every XCD gets one contiguous run of image tiles
     // (row-major: neighbours that walk neighbouring voxels share an L2) cut so that all runs
@@ -981,13 +1014,30 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
       if (aux->order_host != order) {  // unchanged camera: the table on the device is still right
         if ((int)order.size() > aux->order_cap) {
           if (aux->d_order) (void)hipFree(aux->d_order);
+          if (aux->h_order) (void)hipHostFree(aux->h_order);
           aux->d_order = nullptr;
+          aux->h_order = nullptr;
           aux->order_cap = 0;
           hipError_t e = hipMalloc((void **)&aux->d_order, order.size() * sizeof(int));
           if (e != hipSuccess) return e;
+          e = hipHostMalloc((void **)&aux->h_order, order.size() * sizeof(int), hipHostMallocDefault);
+          if (e != hipSuccess) return e;
           aux->order_cap = (int)order.size();
         }
-        hipError_t e = hipMemcpyAsync(aux->d_order, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, s);
+        // pinned staging + a copy ON THE LAUNCH STREAM: a copy from pageable memory is not
+        // stream-ordered against the kernel that follows (seen as wrong tiles when several
+        // contexts render at once).  The staging buffer is rewritten only after its last copy.
+        if (!aux->order_ev) {
+          hipError_t e = hipEventCreateWithFlags(&aux->order_ev, hipEventDisableTiming);
+          if (e != hipSuccess) return e;
+        } else {
+          hipError_t e = hipEventSynchronize(aux->order_ev);
+          if (e != hipSuccess) return e;
+        }
+        memcpy(aux->h_order, order.data(), order.size() * sizeof(int));
+        hipError_t e = hipMemcpyAsync(aux->d_order, aux->h_order, order.size() * sizeof(int), hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return e;
+        e = hipEventRecord(aux->order_ev, s);
         if (e != hipSuccess) return e;
         aux->order_host.swap(order);
       }
@@ -998,11 +1048,11 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
           if (aux->d_trace) (void)hipFree(aux->d_trace);
           aux->d_trace = nullptr;
           aux->trace_cap = 0;
-          hipError_t e = hipMalloc((void **)&aux->d_trace, (size_t)nblocks * 16);
+          hipError_t e = hipMalloc((void **)&aux->d_trace, (size_t)nblocks * 32);
           if (e != hipSuccess) return e;
           aux->trace_cap = nblocks;
         }
-        hipError_t e = hipMemsetAsync(aux->d_trace, 0, (size_t)nblocks * 16, s);
+        hipError_t e = hipMemsetAsync(aux->d_trace, 0, (size_t)nblocks * 32, s);
         if (e != hipSuccess) return e;
         aux->trace_n = nblocks;
         Q.trace = aux->d_trace;

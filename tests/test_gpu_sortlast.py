@@ -28,6 +28,8 @@ def test_sharded_frames_composite_to_whole(gpu_renderer_factory, smk, world, pos
             push_scene(R, sc)
             R.render_device(layers[r].data_ptr(), None, None)
         torch.cuda.synchronize()
+        for R in rs:   # asynchronous frames report kernel-side failures through the status word
+            assert R.stat("slab_status") == 0
         order = rs[0].shard_order(world)
         # the C++ BSP rule agrees with the Python mirror used by the CPU tests
         mv = np.array(sc.mv()).reshape(4, 4).T
