@@ -44,9 +44,13 @@ struct SlabParams {
   long long strideV, strideS;  // voxel strides of the layout in use (U stride is 1)
   int Ou, Ov, Os;              // stored-box origin along U,V,S (global voxel index)
   int Du, Dv, Ds;              // stored-box dims along U,V,S
-  int wu;                      // 16-byte units per window row that are loaded (<= 1 << wp_log2)
+  int wu;                      // 16-byte units per window row that are loaded at most (<= wp)
   int wv;                      // window rows that are loaded
-  int wp_log2;                 // LDS row pitch = (1 << wp_log2) units: one DMA chunk = 64 >> wp_log2 whole rows
+  int wp;                      // LDS row pitch in 16-byte units, a multiple of 8: the slot image is flat with this
+                               // pitch, so the (row, column) a DMA lane serves repeats every `per` chunks = `rpg` rows
+  int per, rpg;                // chunks and rows per group: per = wp / gcd(64, wp), rpg = 64 / gcd(64, wp)
+  int groups;                  // row groups per slice = ceil(wv / rpg); chunks = groups * per
+  int mask_need;               // loaders fetch only what each slice needs of the window (big windows)
   int chunks;                  // DMA wave-instructions per slice = ceil(wv / rows per chunk), uniform
   int slot_bytes;              // chunks * 1024
   int nslots;                  // ring size
@@ -114,7 +118,8 @@ __device__ __forceinline__ void slab_read8_nb8(unsigned a, unsigned ap, unsigned
 struct SlabEnt {
   int base;      // LDS byte address of GLOBAL voxel (u=0, v=0) of this slice's slot image:
                  // corner address = base + v * pitch_bytes + u * voxel_bytes
-  short u0, v0;  // window origin in stored-box voxel coordinates (loader)
+  unsigned pack;  // loader: window origin u0 | v0 << 11 (stored-box voxels), (units the slice needs - 1) << 22,
+                  // min(15, wv - rows the slice needs) << 28
 };
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
@@ -337,8 +342,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   __syncthreads();
   const int smin = ctl[0], smax = ctl[1];
   const int dir = Q.dir, nslots = Q.nslots;
-  const int wp_log2 = Q.wp_log2;
-  const int pitch_log2 = wp_log2 + 4;  // LDS row pitch in bytes = 16 << wp_log2
+  const unsigned pitch_b = 16u * (unsigned)Q.wp;  // LDS row pitch in bytes
   const unsigned ring_addr = (unsigned)(size_t)(lds_cptr_t)smem;
   // positions p = 0..npos-1 in marching order: base slice b(p) = dir>0 ? smin+p : smax-p;
   // load order q = 0..npos: slice L(q) = dir>0 ? smin+q : smax+1-q; position p reads L(p), L(p+1)
@@ -396,10 +400,12 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       // fixed-shape window: slide it back inside the stored box where it would stick out
       const int wu0 = min(u0, Q.Du - wuv), wv0 = min(v0, Q.Dv - Q.wv);
       if (u1 - wu0 + 1 > wuv || v1 - wv0 + 1 > Q.wv) ctl[3] = 2;  // host bound violated: reported, never silent
+      // what this slice really needs of the fixed-shape window (the loader masks the rest)
+      const int need_u = max((u1 - wu0 + UPV) / UPV, 1), need_v = max(v1 - wv0 + 1, 1);
       SlabEnt ent;
-      ent.u0 = (short)wu0;
-      ent.v0 = (short)wv0;
-      ent.base = (int)ring_addr + (q % nslots) * Q.slot_bytes - ((Q.Ov + wv0) << pitch_log2) - (Q.Ou + wu0) * VB;
+      ent.pack = (unsigned)wu0 | ((unsigned)wv0 << 11) | ((unsigned)(min(need_u, Q.wu) - 1) << 22) |
+                 ((unsigned)min(15, max(Q.wv - need_v, 0)) << 28);
+      ent.base = (int)ring_addr + (q % nslots) * Q.slot_bytes - (Q.Ov + wv0) * (int)pitch_b - (Q.Ou + wu0) * VB;
       wtab[e] = ent;
     }
   }
@@ -420,26 +426,32 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       // ================================ loader wave ============================================
       // Streams load indices q = 0..npos in order.  Slot of q is q % nslots; it may be rewritten
       // once every consumer is past position q - nslots (positions < min progress are done).
-      // Every slice is exactly `chunks` DMA wave-instructions (one chunk = 64 >> wp_log2 whole
-      // window rows), so the in-order vmcnt tells which slices have landed.  A lane's source
-      // offset inside the window is the same for every chunk and every slice, so a chunk costs
-      // the wave ~8 scalar instructions + one global_load_lds: measured with tools/dma_probe.hip,
+      // Every slice is exactly `chunks` DMA wave-instructions, so the in-order vmcnt tells which
+      // slices have landed.  The window image is flat on a fixed pitch, so the (row, column) a
+      // lane serves -- its source offset inside the window -- is the same in every group of rows
+      // and every slice, and a chunk costs the wave a few scalar instructions, two compares (the
+      // slice's own extent masks the lanes it does not need) + one global_load_lds: measured with
+      // tools/dma_probe.hip,
       // ONE such wave per CU streams 5.2-5.9 TB/s chip-wide (94-104 cycles per KiB), while a
       // compiler-scheduled loop with per-lane address arithmetic stays at ~415 cycles per KiB
       // whatever the memory behind it -- instruction issue, not HBM, is what a loader must save.
       __builtin_amdgcn_s_setprio(3);  // the stream must never wait for issue slots behind pollers
       const char *gv = reinterpret_cast<const char *>(Q.vox);
-      const int chunks = Q.chunks;
-      const int mych = (chunks - lid + NL - 1) / NL;  // DMA instructions THIS loader issues per slice
-      const bool has_last = (chunks - 1) % NL == lid;  // ... the last of which may be the slice's short chunk
-      const int nfull = has_last ? mych - 1 : mych;
+      // row groups g = lid, lid+NL, ... of every slice are mine; a group is `per` chunks = `rpg` rows
+      const int per = Q.per, rpg = Q.rpg, groups = Q.groups;
+      const int mygroups = (groups - lid + NL - 1) / NL;
+      const int mych = mygroups * per;  // DMA instructions THIS loader issues per slice
       const unsigned strideVb = (unsigned)(Q.strideV * (long long)sizeof(Vox));  // bytes, < 2^32
-      const int rpc = 64 >> wp_log2;                                             // window rows per chunk
-      const int lrow = lane >> wp_log2, lcol = lane & ((1 << wp_log2) - 1);
-      const bool full_ok = lcol < Q.wu;                                    // lanes beyond the window width never load
-      const bool last_ok = full_ok && (chunks - 1) * rpc + lrow < Q.wv;    // nor rows beyond its height (last chunk)
-      const unsigned voff = (unsigned)lrow * strideVb + (unsigned)lcol * 16u;
-      const size_t cstep = (size_t)(NL * rpc) * strideVb;  // source advance from one of my chunks to the next
+      // unit 64*k + lane of a group sits at (row, column) = divmod(64*k + lane, wp): fixed per lane and phase k
+      unsigned voff[7], rowk[7], colk[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const unsigned g = 64u * k + lane;
+        rowk[k] = g / (unsigned)Q.wp;
+        colk[k] = g - rowk[k] * (unsigned)Q.wp;
+        voff[k] = rowk[k] * strideVb + colk[k] * 16u;
+      }
+      const size_t gstep = (size_t)(NL * rpg) * strideVb;  // source advance from one of my groups to the next
       const size_t strideSb = (size_t)Q.strideS * sizeof(Vox);
       const bool l2hot = DIAG && (P.lockstep & 8) != 0;           // (diagnostic: every slice re-reads one slice)
       int q = 0, inflight = 0, landed = 0, idle = 0, minp = 0, slot_q = 0;
@@ -457,10 +469,10 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       // one LDS-DMA wave-instruction: 16 B per active lane from src + voff to LDS dst + lane*16
       // (saddr form: no per-chunk VALU; M0 written in the statement that reads it)
       unsigned keep_m0;
-#define SLAB_DMA(src_, dst_)                                                                                        \
+#define SLAB_DMA(src_, dst_, voff_)                                                                                 \
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" \
                : "=&s"(keep_m0)                                                                                     \
-               : "v"(voff), "s"(dst_), "s"(src_)                                                                    \
+               : "v"(voff_), "s"(dst_), "s"(src_)                                                                   \
                : "memory")
       // table entries of 64 consecutive load indices, one per lane, refreshed every 64 slices:
       // a slice's window origin is then one v_readlane away instead of an LDS round trip
@@ -486,42 +498,64 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             const int ql = q + lane;
             const int e = (dir > 0 ? smin + ql : smax + 1 - ql) - Q.Os;
             ent_uv = -1;
-            if (ql <= npos && e >= 0 && e < Q.Ds) ent_uv = (int)raw_lds_b64(&wtab[e]).y;
+            if (ql <= npos && e >= 0 && e < Q.Ds) ent_uv = (int)raw_lds_b64(&wtab[e]).y;  // (.pack; never -1: u0 < 2^11)
           }
           const int uv = __builtin_amdgcn_readlane(ent_uv, q & 63);
-          const unsigned dst0 = ring_addr + (unsigned)(slot_q * Q.slot_bytes + lid * 1024);
+          const unsigned dst0 = ring_addr + (unsigned)(slot_q * Q.slot_bytes + lid * per * 1024);
           if (uv != -1) {
             const int sl = (dir > 0 ? smin + q : smax + 1 - q) - Q.Os;
-            const unsigned u0 = (unsigned)uv & 0xffffu, v0 = (unsigned)uv >> 16;
+            const unsigned u0 = (unsigned)uv & 0x7ffu, v0 = ((unsigned)uv >> 11) & 0x7ffu;
+            // (small windows: the whole shape -- the saving would not pay for the partial-group path)
+            const unsigned need_u = Q.mask_need ? (((unsigned)uv >> 22) & 0x3fu) + 1u : (unsigned)Q.wu;
+            const unsigned need_v = Q.mask_need ? (unsigned)Q.wv - ((unsigned)uv >> 28) : (unsigned)Q.wv;
             const char *src = gv + (l2hot ? (size_t)0 : (size_t)sl * strideSb) + (size_t)(v0 * strideVb + u0 * (unsigned)VB) +
-                              (size_t)(lid * rpc) * strideVb;
-            if (full_ok) {
-              const char *sp = src;
-              unsigned dp = dst0;
-              int k = nfull;
-              for (; k >= 4; k -= 4) {
-                SLAB_DMA(sp, dp); sp += cstep; dp += NL * 1024;
-                SLAB_DMA(sp, dp); sp += cstep; dp += NL * 1024;
-                SLAB_DMA(sp, dp); sp += cstep; dp += NL * 1024;
-                SLAB_DMA(sp, dp); sp += cstep; dp += NL * 1024;
+                              (size_t)(lid * rpg) * strideVb;
+            unsigned dst = dst0, row0 = (unsigned)(lid * rpg);
+            // per = wp / gcd(64, wp) is 1, 3, 5 or 7 for a pitch that is a multiple of 8 units
+#define SLAB_GROUP(CHUNK)              \
+  CHUNK(0)                             \
+  if (per >= 3) {                      \
+    CHUNK(1) CHUNK(2)                  \
+    if (per >= 5) {                    \
+      CHUNK(3) CHUNK(4)                \
+      if (per >= 7) { CHUNK(5) CHUNK(6) } \
+    }                                  \
+  }
+            // Lanes outside what THIS slice needs of the window stay idle (the fixed shape is sized
+            // for the widest section of the bundle; at a voxel per pixel the mean need is ~70 % of
+            // it).  Column masks are per slice; only a group that the needed rows end in pays a
+            // per-lane row test, and there lane 0 always loads so that every slice is the same
+            // number of wave-instructions (the in-order vmcnt counts slices).
+            bool cm[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) cm[k] = k < per && colk[k] < need_u;
+            for (int g = 0; g < mygroups; ++g) {
+              if (row0 + (unsigned)rpg <= need_v) {
+#define SLAB_CHUNK_ROWS_OK(k) \
+  if (cm[k]) SLAB_DMA(src, dst + k * 1024u, voff[k]);
+                SLAB_GROUP(SLAB_CHUNK_ROWS_OK)
+#undef SLAB_CHUNK_ROWS_OK
+              } else {
+#define SLAB_CHUNK_MASKED(k)                                                                  \
+  {                                                                                           \
+    const bool in_need = cm[k] && row0 + rowk[k] < need_v;                                    \
+    const unsigned vo = in_need ? voff[k] : 0u; /* lane 0 re-reads the group's first unit */  \
+    if (in_need || lane == 0) SLAB_DMA(src, dst + k * 1024u, vo);                             \
+  }
+                SLAB_GROUP(SLAB_CHUNK_MASKED)
+#undef SLAB_CHUNK_MASKED
               }
-              if (k & 2) {
-                SLAB_DMA(sp, dp); sp += cstep; dp += NL * 1024;
-                SLAB_DMA(sp, dp); sp += cstep; dp += NL * 1024;
-              }
-              if (k & 1) SLAB_DMA(sp, dp);
+              src += gstep;
+              dst += (unsigned)(NL * per * 1024);
+              row0 += (unsigned)(NL * rpg);
             }
-            if (has_last && last_ok) {  // (operands recomputed from uniform values: sp/dp above live in a divergent region)
-              const char *sl_src = src + (size_t)nfull * cstep;
-              const unsigned sl_dst = dst0 + (unsigned)(nfull * NL * 1024);
-              SLAB_DMA(sl_src, sl_dst);
-            }
+#undef SLAB_GROUP
           } else {
             // slice outside the stored box (never read): keep the instruction count uniform
             unsigned dst = dst0;
-            for (int c = lid; c < chunks; c += NL) {
-              SLAB_DMA(gv, dst);
-              dst += NL * 1024;
+            for (int c = 0; c < mych; ++c) {
+              SLAB_DMA(gv, dst, voff[0] * 0u);
+              dst += 1024u;
             }
           }
           ++q;
@@ -586,7 +620,6 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       // table row of the sample's base slice: entry index = bs - Os = psgn*pb + (-psgn*poff - Os)
       const int eoff = -psgn * poff - Q.Os;
       const unsigned wtab_addr = (unsigned)(size_t)(lds_cptr_t)wtab;
-      const unsigned pitch_b = 16u << wp_log2;
       for (int it = 0;; ++it) {
         const bool want = pb < SLAB_DONE;
         if (!__any(want)) break;  // every ray of this wave is finished
@@ -653,7 +686,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           smk_lin_clamp(p1, P.N[1], y0, y1, fy);
           smk_lin_clamp(p2, P.N[2], z0, z1, fz);
           const int iu = AU == 0 ? x0 : y0, iv = AV == 1 ? y0 : z0;  // global voxel indices
-          const unsigned lo_off = ((unsigned)iv << pitch_log2) + ((unsigned)iu << VBL);
+          const unsigned lo_off = __umul24((unsigned)iv, pitch_b) + ((unsigned)iu << VBL);  // (24-bit multiply: full rate)
           const unsigned a0 = (unsigned)base_a + lo_off, b0 = (unsigned)base_b + lo_off;
           // corners <ds><dv><du> -> model order <dx><dy><dz>; lerp order x, y, z like the gather kernel
 #define QI(dx, dy, dz) (PERM == 0 ? ((dz) * 4 + (dy) * 2 + (dx)) : PERM == 1 ? ((dy) * 4 + (dz) * 2 + (dx)) : ((dx) * 4 + (dz) * 2 + (dy)))
@@ -857,7 +890,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
   // (one loader wave moves ~10 B/cycle at best, MI355X_MICROARCH.md 'ldsdma-fill'; a heavy
   //  stream needs several per CU)
   struct Cfg { int tw, th, nl; };
-  Cfg cfgs[2] = {{32, 16, 1}, {32, 24, 4}};
+  Cfg cfgs[2] = {{32, 16, 2}, {32, 24, 4}};
   int ncfg = 2;
   if (opt_tile == 1) { cfgs[0] = {16, 16, 1}; ncfg = 1; }
   else if (opt_tile == 2) { cfgs[0] = {24, 32, 4}; ncfg = 1; }
@@ -946,17 +979,25 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     Wu = std::min(Wu, Q.Du);
     Wv = std::min(Wv, Q.Dv);
     if (Wu < 2 || Wv < 2) { *why = "degenerate window"; return hipErrorNotSupported; }
-    // fixed window shape: wu 16-byte units per row on an LDS pitch of the next power of two (so a
-    // DMA chunk is 64 >> wp_log2 WHOLE rows and a lane's offset in the window is a constant)
+    // fixed window shape: wu 16-byte units per row on an LDS pitch of the next multiple of 8 units
+    // (128 B); the slot image is flat, so the (row, column) a DMA lane serves repeats every
+    // per = wp / gcd(64, wp) chunks = rpg = 64 / gcd(64, wp) rows ("group")
     Q.wu = Wu / upv;
     Q.wv = Wv;
     if (Q.wu > 64) { if (ci + 1 < ncfg) continue; *why = "window wider than one DMA chunk"; return hipErrorNotSupported; }
-    Q.wp_log2 = 0;
-    while ((1 << Q.wp_log2) < Q.wu) ++Q.wp_log2;
-    const int rpc = 64 >> Q.wp_log2;
-    Q.chunks = (Q.wv + rpc - 1) / rpc;
+    if (Q.Du > 2047 || Q.Dv > 2047) { *why = "stored box wider than 2047 voxels across the view"; return hipErrorNotSupported; }
+    Q.wp = (Q.wu + 7) & ~7;
+    {
+      int g = 64, r = Q.wp;
+      while (r) { int t = g % r; g = r; r = t; }  // gcd(64, wp)
+      Q.per = Q.wp / g;
+      Q.rpg = 64 / g;
+    }
+    Q.groups = (Q.wv + Q.rpg - 1) / Q.rpg;
+    Q.chunks = Q.groups * Q.per;
     Q.slot_bytes = Q.chunks * 1024;
-    if (Q.chunks > 63) { if (ci + 1 < ncfg) continue; *why = "window needs more than 63 DMA chunks"; return hipErrorNotSupported; }
+    Q.mask_need = Q.chunks >= 12 ? 1 : 0;
+    if ((Q.groups + nl - 1) / nl * Q.per > 63) { if (ci + 1 < ncfg) continue; *why = "window needs more than 63 DMA chunks per loader"; return hipErrorNotSupported; }
     // light enough for this configuration?  otherwise try the next (heavier-duty) one
     if (ci + 1 < ncfg && (double)Q.chunks * 1024.0 / (nw * 64) > 16.0 * nl) continue;
 
@@ -976,15 +1017,18 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     }
     if (ns < 3) { if (ci + 1 < ncfg) continue; *why = "window does not fit LDS"; return hipErrorNotSupported; }
     Q.nslots = ns;
-    const int mych = (Q.chunks + nl - 1) / nl;  // most DMA instructions one loader issues per slice
+    const int mych = (Q.groups + nl - 1) / nl * Q.per;  // most DMA instructions one loader issues per slice
     Q.maxfly = std::max(1, std::min(ns, 63 / mych + 1));
-    Q.wstep = std::max(0, std::min((int)ceil(fabs(Bc[as])), ns - 3));
+    // a deep ring lets the whole band step together (every lane active); on a short one a wave that
+    // waits for its whole band leaves the loaders nothing to overlap with (measured, 1024^3: 5 slots,
+    // wstep 0 / 1 / 2 -> 5.5 / 5.8 / 6.8 ms)
+    Q.wstep = std::max(0, std::min((int)ceil(fabs(Bc[as])), ns - 5));
     if (opt_T > 0) Q.wstep = std::max(0, std::min(opt_T - 1, ns - 3));  // (experiment knob: slab_T = wstep + 1)
     Q.pmask = ns >= 2 * band ? 1 : 0;
     const size_t lds = (size_t)ns * Q.slot_bytes + fixed;
     if (getenv("SMK_DEBUG"))
-      fprintf(stderr, "[smk] slice-ring plan: tile %dx%d, %d+%d waves, window %d units x %d rows (pitch %d), %d chunks/slice, %d slots of %d B, table+ctl %zu B, LDS %zu B, band %d, wstep %d, pmask %d, maxfly %d\n",
-              tw, th, nw, nl, Q.wu, Q.wv, 1 << Q.wp_log2, Q.chunks, ns, Q.slot_bytes, fixed, lds, band, Q.wstep, Q.pmask, Q.maxfly);
+      fprintf(stderr, "[smk] slice-ring plan: tile %dx%d, %d+%d waves, window %d units x %d rows (pitch %d units), %d chunks/slice, %d slots of %d B, table+ctl %zu B, LDS %zu B, band %d, wstep %d, pmask %d, maxfly %d\n",
+              tw, th, nw, nl, Q.wu, Q.wv, Q.wp, Q.chunks, ns, Q.slot_bytes, fixed, lds, band, Q.wstep, Q.pmask, Q.maxfly);
     // ---- schedule.  Blocks are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8, in
     // order of b), each XCD with its own L2.  Every XCD gets one contiguous run of image tiles
     // (row-major: neighbours that walk neighbouring voxels share an L2) cut so that all runs
