@@ -77,7 +77,7 @@ extern "C" void smk_destroy(smk_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   free_volume(c);
-  void *ptrs[] = {c->d_tlut, c->d_tf_vg, c->d_tf_h, c->d_tf3d, c->d_noise, c->d_out, c->d_depth};
+  void *ptrs[] = {c->d_tlut, c->d_tf_vg, c->d_tf_h, c->d_tf3d, c->d_tf_occ, c->d_noise, c->d_out, c->d_depth};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->slab.h_status) (void)hipHostFree(c->slab.h_status);
@@ -553,6 +553,24 @@ static int refresh_tf2d(smk_ctx *c, const smk_raycoef &rc) {
       c->h_tf_eff[i * 4 + 3] = (unsigned char)(int)((1.0 - pow((1.0 - (c->h_tf_vg[i * 4 + 3] / 255.0)), alphaScale)) * 255);
   }
   if (dev_replace(c, &c->d_tf_vg, c->h_tf_eff.data(), n * 4)) return 1;
+  // occupancy bitmap of the effective table: bit (t, s) is set when any of the four texels a
+  // bilinear lookup with base texel (s, t) touches has alpha != 0.  A clear bit means the lookup
+  // returns alpha == 0 EXACTLY (lerps of zeros), so a kernel may skip the fetch without changing
+  // a single bit of the frame.
+  {
+    const int sv = c->sv, sg = c->sg, roww = (sv + 31) / 32;
+    std::vector<uint32_t> occ((size_t)roww * sg, 0u);
+    for (int t = 0; t < sg; ++t)
+      for (int sx = 0; sx < sv; ++sx) {
+        const int s1 = std::min(sx + 1, sv - 1), t1 = std::min(t + 1, sg - 1);
+        const unsigned char *e = c->h_tf_eff.data();
+        if (e[((size_t)t * sv + sx) * 4 + 3] | e[((size_t)t * sv + s1) * 4 + 3] | e[((size_t)t1 * sv + sx) * 4 + 3] |
+            e[((size_t)t1 * sv + s1) * 4 + 3])
+          occ[(size_t)t * roww + (sx >> 5)] |= 1u << (sx & 31);
+      }
+    if (dev_replace(c, &c->d_tf_occ, occ.data(), occ.size() * 4)) return 1;
+    c->tf_occ_roww = roww;
+  }
   c->tf_rate_applied = sr;
   c->tf_dirty = false;
   return 0;
@@ -725,6 +743,8 @@ static int build_params(smk_ctx *c, RenderParams &P) {
   P.tlut_size = c->tlut_size;
   P.tf_vg = c->d_tf_vg;
   P.tf_h = c->d_tf_h;
+  P.tf_occ = c->tf_mode == 1 ? c->d_tf_occ : nullptr;
+  P.occ_roww = c->tf_occ_roww;
   P.sv = c->sv;
   P.sg = c->sg;
   // third-axis data modes (NV20VolRen3D.cpp:686-693, 813-819)

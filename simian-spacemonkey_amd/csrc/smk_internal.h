@@ -33,6 +33,8 @@ struct RenderParams {
   int tlut_size;
   const uint32_t *tf_vg;  // [sg][sv] RGBA8
   const uint32_t *tf_h;   // [sg][sv] RGBA8 (alpha used) or null
+  const uint32_t *tf_occ;  // [sg][occ_roww] bit s of row t: the bilinear lookup based at texel (s,t) can be non-transparent
+  int occ_roww;
   int sv, sg, third_axis;
   const uint32_t *tf3d;  // [s3h][s3g][s3v]
   int s3v, s3g, s3h;
@@ -104,6 +106,8 @@ struct smk_ctx {
   int tlut_size = 0;
   std::vector<unsigned char> h_tf_vg, h_tf_h, h_tf_eff;
   uint32_t *d_tf_vg = nullptr, *d_tf_h = nullptr, *d_tf3d = nullptr;
+  uint32_t *d_tf_occ = nullptr;  // occupancy bitmap of the effective (V,G) table, tf_occ_roww words per row
+  int tf_occ_roww = 0;
   int sv = 0, sg = 0, s3v = 0, s3g = 0, s3h = 0;
   bool tf_dirty = true;
   float tf_rate_applied = -1.f;
