@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def pmc(d, name):
     out = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == name:
                 out[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
@@ -29,7 +29,7 @@ def pmc(d, name):
 def main():
     tag, kt, fd, wd = sys.argv[1:5]
     prof = os.path.join(ROOT, "profiles")
-    for f in glob.glob(os.path.join(kt, "*", "*_kernel_stats.csv")):
+    for f in glob.glob(os.path.join(kt, "**", "*_kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(prof, tag + "_kernel_stats.csv"))
     fetch, write = pmc(fd, "FETCH_SIZE"), pmc(wd, "WRITE_SIZE")
     traffic = {}
