@@ -515,7 +515,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             // (small windows: the whole shape -- the saving would not pay for the partial-group path)
             const unsigned need_u = Q.mask_need ? (((unsigned)uv >> 22) & 0x3fu) + 1u : (unsigned)Q.wu;
             const unsigned need_v = Q.mask_need ? (unsigned)Q.wv - ((unsigned)uv >> 28) : (unsigned)Q.wv;
-            const char *src = gv + (l2hot ? (size_t)0 : (size_t)sl * strideSb) + (size_t)(v0 * strideVb + u0 * (unsigned)VB) +
+            const char *src = gv + (l2hot ? (size_t)0 : (size_t)sl * strideSb) + ((size_t)v0 * strideVb + (size_t)u0 * VB) +  // (64-bit: v0 * strideVb passes 4 GiB when V is the slowest axis of a 1024^3 volume)
                               (size_t)(lid * rpg) * strideVb;
             unsigned dst = dst0, row0 = (unsigned)(lid * rpg);
             // per = wp / gcd(64, wp) is 1, 3, 5 or 7 for a pitch that is a multiple of 8 units
@@ -1038,6 +1038,9 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     // a wave holds ceil(slices per plane) + 1 slices while it works and the loaders want a few in flight
     const int band = (int)ceil(fabs(Bc[as])) + 2;
     if (ns < band + 2 && 158 * 1024 > fixed) {
+      // the ring of a small workgroup does not fit half a CU: one workgroup per CU it is -- then
+      // rather the big tile with 16 waves than this one with 10
+      if (ci + 1 < ncfg && budget < 158 * 1024) continue;
       ns = (int)((158 * 1024 - fixed) / (size_t)Q.slot_bytes);
       if (ns > band + 4) ns = band + 4;
     }

@@ -124,3 +124,49 @@ def test_forced_slab_reports_why_it_cannot_run(R, smk):
     with pytest.raises(smk.SmkError, match="gather-only|not applicable"):
         R.render()
     R.set_option("kernel", 0)
+
+
+def test_byte_offsets_beyond_4_gib_inside_a_slice_stride(gpu_renderer_factory):
+    """S = y on a 512 x 512 x 1100 f32 volume: the window's V axis is z, whose stride is 4 MiB, so
+    window origins above z = 1024 sit more than 4 GiB into the slab of one y-slice -- 32-bit
+    byte arithmetic in the loaders passes every small-volume test and fails here.  No CPU
+    reference at this size: the gather kernel (itself checked against the CPU at small sizes)
+    is the reference, bit for bit."""
+    import torch
+    from _scenes import POSES, tf_cfg3, tf_h
+    import oracle as O
+    dims = (512, 512, 1100)
+    r = gpu_renderer_factory()
+    try:
+        nx, ny, nz = dims
+        scalar = torch.empty((nz, ny, nx), dtype=torch.uint8, device="cuda")
+        r.synth_volume_device(0, 3, dims, scalar.data_ptr())
+        vgh8 = torch.empty((nz, ny, nx, 3), dtype=torch.uint8, device="cuda")
+        vghf = torch.empty((nz, ny, nx, 3), dtype=torch.float32, device="cuda")
+        r.make_vgh_device(scalar.data_ptr(), 0, dims, 1, vgh8.data_ptr(), vghf.data_ptr())
+        nrm = torch.empty((nz, ny, nx, 3), dtype=torch.uint8, device="cuda")
+        r.normals_vgh_device(vgh8.data_ptr(), 3, dims, 0, nrm.data_ptr())
+        del scalar, vgh8
+        r.upload_volume_device(vghf.data_ptr(), dims, 3, 1, nrm.data_ptr())
+        del vghf, nrm
+        torch.cuda.empty_cache()
+        sc = O.Scene(np.zeros((2, 2, 2, 3), np.float32))       # camera / shading parameters only
+        sc.dims, sc.fsize = dims, tuple(np.float32(d / 1100.0) for d in dims)
+        sc.xform = O.rotation(*POSES["y+"])
+        sc.width = sc.height = 768          # ~1.4 voxels per pixel: windows must fit one DMA row
+        sc.steps = 192
+        r.set_option("tf_raw", 1)
+        r.set_tf2d(tf_cfg3(), tf_h(0.5))
+        r.set_camera(sc.mv(), sc.frustum, (sc.znear, 20.0), sc.width, sc.height)
+        r.set_sampling(0.0, sc.steps, 1.0, 1)
+        r.set_shading("r8k", sc.light_pos, sc.eye, sc.at, sc.xform, sc.intens)
+        r.set_perturb(None, None, None)
+        r.set_option("kernel", 1)
+        a = r.render()
+        r.set_option("kernel", 2)
+        b = r.render()
+        assert r.last_frame_info()[0] == 2
+        assert a[..., 3].max() > 0.05
+        assert np.array_equal(a, b), "slab and gather kernels differ: %g" % np.abs(a - b).max()
+    finally:
+        r.close()

@@ -57,6 +57,9 @@ def main():
             t, kms, kn = bench.timed(r, a.frames, 2, frame, 1, None)
         kern, _, alg = r.last_frame_info()
         img = frame.cpu().numpy()
+        st = r.stat("slab_status")
+        if st:
+            print("   !! slice-ring kernel status %d (1 = time-out, 2 = window outside its host bound): frame invalid" % st, flush=True)
         if base is None:
             base = img
         err = float(np.abs(img - base).max())
