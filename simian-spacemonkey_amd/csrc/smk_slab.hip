@@ -215,6 +215,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   typedef typename VoxT<DT>::type Vox;
   constexpr int UPV = DT == 0 ? 2 : 1;   // voxels per 16-byte DMA unit
   constexpr int VB = DT == 0 ? 8 : 16;   // bytes per voxel
+  // (global_load_lds_dwordx3 does NOT compact: it writes 12 bytes per lane at a 16-byte lane stride
+  //  -- tools/dma_layout_probe.hip -- so staging only {c0,c1,c2} needs a 12-byte HBM plane)
   constexpr int VBL = DT == 0 ? 3 : 4;   // log2
   constexpr int NTH = (NW + NL) * 64;
   extern __shared__ __align__(16) unsigned char smem[];

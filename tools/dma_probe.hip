@@ -119,7 +119,7 @@ __global__ void probe_lean(const char *buf, size_t bufbytes, int nchunks, int nw
 // lean loop over scattered row pieces: every wave-instruction fetches ROWS rows of 1024/ROWS bytes
 // (ROWS = 1, 2, 4), rows 16 KiB apart, slices 16 MiB apart; every workgroup walks the slices from
 // its own phase (as image tiles at different depths do) from an origin that is only 16-B aligned
-template <int ROWS, int DEPHASE>
+template <int ROWS, int DEPHASE, int BYTES = 16>
 __global__ void probe_rows(const char *buf, int nchunks, int nwaves, int active_lanes, long long *cycles) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -141,10 +141,16 @@ __global__ void probe_rows(const char *buf, int nchunks, int nwaves, int active_
       const char *src = buf + (size_t)((sl + phase) % 1000) * ((size_t)16384 * 1024) + origin + (size_t)(wave * ROWS) * 16384;
       for (int r = wave * ROWS; r < rows_per_slice; r += nwaves * ROWS) {
         const unsigned dst = ring + (unsigned)(issued & 31) * 1024;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(voff), "s"(dst), "s"(src)
-                     : "memory");
+        if (BYTES == 16)
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep)
+                       : "v"(voff), "s"(dst), "s"(src)
+                       : "memory");
+        else  // 12 of every 16 bytes: LDS image with 12-byte lanes
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, %3\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep)
+                       : "v"(voff), "s"(dst), "s"(src)
+                       : "memory");
         src += (size_t)(nwaves * ROWS) * 16384;
         ++issued;
         if ((issued & 7) == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -221,9 +227,9 @@ static int run_lean(const char *buf, size_t bytes, int nwaves, int wgs, int nchu
   return 0;
 }
 
-template <int ROWS, int DEPHASE>
+template <int ROWS, int DEPHASE, int BYTES = 16>
 static int run_rows(const char *buf, int nwaves, int wgs, int active, int nchunks, long long *d_cyc) {
-  auto k = probe_rows<ROWS, DEPHASE>;
+  auto k = probe_rows<ROWS, DEPHASE, BYTES>;
   size_t lds = (size_t)nwaves * 32 * 1024;
   CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   hipEvent_t e0, e1;
@@ -238,8 +244,8 @@ static int run_rows(const char *buf, int nwaves, int wgs, int active, int nchunk
   float ms = 0;
   CK(hipEventElapsedTime(&ms, e0, e1));
   double bytes = (double)wgs * nwaves * nchunks * (ROWS * active * 16.0);
-  printf("rows     %d x %4d B per instr (lanes %2d/%2d)  dephased %d  waves/WG %d: %7.3f ms  %7.1f GB/s chip\n", ROWS, active * 16, active,
-         64 / ROWS, DEPHASE, nwaves, ms, bytes / ms / 1e6);
+  printf("rows     %d x %4d B per instr (lanes %2d/%2d, %2d of 16 B to LDS)  dephased %d  waves/WG %d: %7.3f ms  %7.1f GB/s chip (source bytes)\n", ROWS, active * 16, active,
+         64 / ROWS, BYTES, DEPHASE, nwaves, ms, bytes / ms / 1e6);
   fflush(stdout);
   return 0;
 }
@@ -253,6 +259,8 @@ int main(int argc, char **argv) {
   CK(hipMalloc((void **)&d_cyc, 8 * 65536));
   const int nchunks = 8192;  // 8 MiB per wave
   for (int nw : {1, 2, 4}) {
+    if (run_rows<2, 1, 12>(buf, nw, 256, 32, nchunks / nw, d_cyc)) return 1;
+    if (run_rows<2, 1, 12>(buf, nw, 256, 30, nchunks / nw, d_cyc)) return 1;
     if (run_rows<2, 0>(buf, nw, 256, 32, nchunks / nw, d_cyc)) return 1;
     if (run_rows<2, 1>(buf, nw, 256, 32, nchunks / nw, d_cyc)) return 1;
     if (run_rows<2, 1>(buf, nw, 256, 30, nchunks / nw, d_cyc)) return 1;
@@ -261,7 +269,7 @@ int main(int argc, char **argv) {
     if (run_rows<4, 1>(buf, nw, 256, 16, nchunks / nw, d_cyc)) return 1;
   }
   return 0;
-  for (int nw : {1, 2, 4}) {
+  for (int nw : {1}) {
     if (run_lean<8>(buf, bytes, nw, 256, nchunks, d_cyc)) return 1;
     if (run_lean<24>(buf, bytes, nw, 256, nchunks, d_cyc)) return 1;
     if (nw < 4 && run_lean<48>(buf, bytes, nw, 256, nchunks, d_cyc)) return 1;
