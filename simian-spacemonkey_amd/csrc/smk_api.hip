@@ -252,6 +252,8 @@ static int upload_impl(smk_ctx *c, const smk_volume_desc *b, int nb, int nelts, 
   if (d_stage) (void)hipFree(d_stage);
   if (d_gstage) (void)hipFree(d_gstage);
   c->have_volume = true;
+  c->tune_choice.clear();  // a new volume: the kernels' relative speed is measured afresh
+  c->tune_sig = 0;
   c->tf_dirty = true;
   return 0;
 }
@@ -858,7 +860,46 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
   // no perturbation, rays sharing one principal axis), the generic gather kernel otherwise
   c->last_kernel = 1;
   c->slab_why.clear();
-  if (c->opt_kernel != 1 && c->tf_mode == 1) {
+  // ---- auto mode: which kernel for this configuration?
+  bool try_slab = c->opt_kernel != 1 && c->tf_mode == 1;
+  unsigned long long sig = 0;
+  int trial = -1;  // 0 / 1: this frame is the slice-ring / gather trial of a new configuration
+  if (c->opt_kernel == 0 && c->tf_mode == 1) {
+    int as = 0;
+    for (int a = 1; a < 3; ++a)
+      if (fabsf(P.rc.Bc[a]) > fabsf(P.rc.Bc[as])) as = a;
+    const unsigned long long f[] = {(unsigned long long)c->dtype, (unsigned long long)c->nelts, (unsigned long long)c->D[0],
+                                    (unsigned long long)c->D[1], (unsigned long long)c->D[2], (unsigned long long)c->W,
+                                    (unsigned long long)c->H, (unsigned long long)P.rc.nplanes, (unsigned long long)shade_kind_of(c),
+                                    (unsigned long long)P.third_axis, (unsigned long long)(as * 2 + (P.rc.Bc[as] > 0)),
+                                    (unsigned long long)c->sv, (unsigned long long)c->sg, (unsigned long long)(d_depth != nullptr),
+                                    (unsigned long long)P.pert_on};
+    sig = 1469598103934665603ull;
+    for (unsigned long long v : f) sig = (sig ^ v) * 1099511628211ull;
+    auto it = c->tune_choice.find(sig);
+    if (it != c->tune_choice.end()) {
+      try_slab = it->second == 2;
+    } else {
+      if (c->tune_sig != sig) {
+        c->tune_sig = sig;
+        c->tune_state = 0;
+      }
+      if (c->tune_state == 2) {  // both trials issued: decide once their events have completed
+        float ms_s = 0, ms_g = 0;
+        if (hipEventQuery(c->tev1[c->tune_slot[0]]) == hipSuccess && hipEventQuery(c->tev1[c->tune_slot[1]]) == hipSuccess &&
+            hipEventElapsedTime(&ms_s, c->tev0[c->tune_slot[0]], c->tev1[c->tune_slot[0]]) == hipSuccess &&
+            hipEventElapsedTime(&ms_g, c->tev0[c->tune_slot[1]], c->tev1[c->tune_slot[1]]) == hipSuccess) {
+          c->tune_choice[sig] = ms_s <= ms_g ? 2 : 1;
+          try_slab = ms_s <= ms_g;
+        }  // else: keep the slice-ring kernel for this frame and ask again
+        (void)hipGetLastError();
+      } else {
+        trial = c->tune_state;
+        try_slab = trial == 0;
+      }
+    }
+  }
+  if (try_slab) {
     if (!c->slab.h_status) {
       HIPCHK(c, hipHostMalloc((void **)&c->slab.h_status, sizeof(int), hipHostMallocMapped));
       *c->slab.h_status = 0;
@@ -879,6 +920,10 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
     else if (e == hipErrorNotSupported) {
       c->slab_why = why ? why : "?";
       if (c->opt_kernel == 2) FAIL(c, "smk_render: slab kernel forced but not applicable: %s", c->slab_why.c_str());
+      if (c->opt_kernel == 0) {  // nothing to choose between for this configuration
+        c->tune_choice[sig] = 1;
+        trial = -1;
+      }
     } else
       HIPCHK(c, e);
   } else if (c->opt_kernel == 2) {
@@ -886,6 +931,10 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
   }
   if (c->last_kernel == 1) HIPCHK(c, smk_launch_gather(P, c->dtype, c->tf_mode, shade_kind_of(c), s));
   HIPCHK(c, hipEventRecord(c->ev1, s));
+  if (trial >= 0) {
+    c->tune_slot[trial] = slot;
+    c->tune_state = trial + 1;
+  }
   c->tcount++;
   return 0;
 }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -142,6 +143,12 @@ struct smk_ctx {
   int opt_kernel = 0, opt_slab_T = 0, opt_tf_raw = 0, opt_tile = 0;
   int opt_wave_w = 8, opt_blk_w = 2, opt_lockstep = 1;
   SlabAux slab;  // slice-ring kernel side buffers
+  // auto mode (option kernel = 0) picks the ray-marcher by measurement: the first frames of a
+  // new configuration run the slice-ring kernel, then the gather kernel (bit-identical frames),
+  // and the faster one is kept for that configuration
+  std::map<unsigned long long, int> tune_choice;
+  unsigned long long tune_sig = 0;
+  int tune_state = 0, tune_slot[2] = {0, 0};
   int last_kernel = 0;
   float last_ms = 0;
   double last_alg_bytes = 0;
