@@ -1,31 +1,31 @@
 // smk_slab.hip -- kernel S: the slice-ring ray-marcher (the fast path for 2-D / separable
-// classification without perturbation).
+// classification without perturbation or depth output).  DESIGN.md section 4 has the measurements
+// behind every choice below.
 //
-// Idea.  The gather kernel (smk_gather.hip) pulls 8 corners per sample through TA/L1: every
-// 128-B line is re-requested from L2 several times and waves spend ~87 % of their time in
-// s_waitcnt (profiles/r01_*).  Here the volume is streamed instead:
+// The gather kernel (smk_gather.hip) pulls 8 corners per sample through TA/L1: every 128-B line
+// is re-requested from L2 several times and waves spend ~87 % of their time in s_waitcnt.  Here
+// the volume is streamed instead:
 //
 //   * the principal axis S of the view (largest |ray direction| component in voxel space) is
-//     chosen on the host; U is the memory-contiguous axis, V the third one;
-//   * a workgroup owns a TW x TH pixel tile: NW consumer waves (one lane = one ray, a wave = a
-//     compact 8x8 sub-tile) plus ONE loader wave;
-//   * the loader wave streams, front to back, the (u,v) window of every S-slice the tile's ray
-//     bundle crosses -- whole contiguous row pieces, 16 B per lane -- from HBM straight into
-//     an LDS ring with LDS-DMA (global_load_lds_dwordx4: no VGPR round trip).  It keeps
-//     several slices in flight behind a COUNTED s_waitcnt vmcnt(N) and publishes a `landed`
-//     counter; the consumers' transfer-function gathers never wait behind the stream because
-//     vmcnt is per wave;
-//   * every consumer wave advances on its own (no workgroup barrier in the main loop): it
-//     waits for `landed`, takes the samples whose base slice is resident, reading the 8
-//     corners from LDS (ds_read_b128 / b64), and publishes its progress; the loader reuses a
-//     ring slot once every wave is past it;
+//     chosen on the host; U is the memory-contiguous axis, V the third one (a lazily built
+//     x-major copy of the volume serves S = x);
+//   * a workgroup owns a pixel tile: NW consumer waves (one lane = one ray, a wave = a compact
+//     8x8 sub-tile) plus NL loader waves;
+//   * the loaders stream, front to back, the (u,v) window of every S-slice the tile's ray bundle
+//     crosses from HBM straight into an LDS ring with LDS-DMA (global_load_lds_dwordx4, no VGPR
+//     round trip): a lean issue loop (scalar address bumps, per-slice lane masks), a counted
+//     s_waitcnt vmcnt(N) that retires the oldest slice in flight, a `landed` word per loader;
+//   * every consumer wave advances on its own (no workgroup barrier in the main loop): one
+//     sample per lane and iteration, taken when the two slices it touches have landed; the 8
+//     corners come from LDS in one batch of reads behind one wait; the wave's progress (minimum
+//     over its lanes) lets the loaders recycle ring slots;
 //   * RGBA stays in registers front to back; 16 B per pixel leave the kernel.
 //
-// Each voxel row piece a tile needs is read once per tile; neighbouring tiles share only the
-// 1-3 voxel fringe (served by the XCD's L2 because tiles are dealt to XCDs in contiguous runs).
+// Each voxel row piece a tile needs is read once per tile; neighbouring tiles share the fringe
+// (served by the XCD's L2: tiles are dealt to XCDs in contiguous, equal-work runs).
 //
 // Sample placement, membership and interpolation order are EXACTLY those of the gather kernel
-// (same fma chains), so the two kernels and the CPU checker agree bit for bit on positions.
+// (same fma chains), so the two kernels agree bit for bit and the CPU checker on positions.
 // Reference semantics: see smk_device.h.
 #include <math.h>
 #include <stdio.h>
@@ -1033,7 +1033,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     Q.use_occ = (Q.fast_tf && Q.mask_need && P.tf_occ && occ_bytes > 0 && occ_bytes <= 8192) ? 1 : 0;
     const size_t fixed = (size_t)Q.Ds * sizeof(SlabEnt) + (8 + 32) * 4 + 64 + (Q.use_ah ? (size_t)P.sv * 4 : 0) + (Q.use_occ ? occ_bytes : 0);
     // ring: as many slots as fit two workgroups per CU (small tiles) or one (big tiles)
-    size_t budget = (nw + nl) * 64 > 640 ? 158 * 1024 : (P.wave_w == 4 ? 52 * 1024 : 78 * 1024);  // (wave_w: experiment knob)
+    size_t budget = (nw + nl) * 64 > 640 ? 158 * 1024 : 78 * 1024;
     if (budget <= fixed) { *why = "slice table does not fit LDS"; return hipErrorNotSupported; }
     int ns = (int)((budget - fixed) / (size_t)Q.slot_bytes);
     if (ns > 24) ns = 24;
