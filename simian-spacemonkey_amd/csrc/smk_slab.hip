@@ -103,6 +103,12 @@ typedef float v3f __attribute__((ext_vector_type(3)));
 // f32 voxels {c0, c1, c2, normal bits}: first two / three channels
 __device__ __forceinline__ void slab_read8(unsigned a, unsigned ap, unsigned b, unsigned bp, v2f (&q)[8]) { SLAB_READ8("ds_read_b64", "16"); }
 __device__ __forceinline__ void slab_read8(unsigned a, unsigned ap, unsigned b, unsigned bp, v3f (&q)[8]) { SLAB_READ8("ds_read_b96", "16"); }
+// whole voxels (normals included) in one batch: workgroups that own a CU alone have the registers
+// for it, and can then release their ring slots before classification and shading (EARLY below)
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void slab_read8_full(unsigned a, unsigned ap, unsigned b, unsigned bp, v4f (&q)[8]) { SLAB_READ8("ds_read_b128", "16"); }
+__device__ __forceinline__ void slab_read8_full(unsigned a, unsigned ap, unsigned b, unsigned bp, v2u (&q)[8]) { SLAB_READ8("ds_read_b64", "8"); }
 // u8 voxels {4 data bytes, normal bits}: the data dword
 __device__ __forceinline__ void slab_read8_u8(unsigned a, unsigned ap, unsigned b, unsigned bp, uint32_t (&q)[8]) { SLAB_READ8("ds_read_b32", "8"); }
 // the packed normals of the same 8 corners (dword NOFF of the voxel)
@@ -219,6 +225,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   //  -- tools/dma_layout_probe.hip -- so staging only {c0,c1,c2} needs a 12-byte HBM plane)
   constexpr int VBL = DT == 0 ? 3 : 4;   // log2
   constexpr int NTH = (NW + NL) * 64;
+  // big workgroups (one per CU, 128 VGPRs each): read whole voxels, release ring slots early
+  constexpr bool EARLY = (NW + NL) > 10;
   extern __shared__ __align__(16) unsigned char smem[];
   // LDS carve: ring [nslots][slot_bytes] | slice table [Ds] | control words | alpha_H
   SlabEnt *wtab = reinterpret_cast<SlabEnt *>(smem + (size_t)Q.nslots * Q.slot_bytes);
@@ -635,7 +643,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
         // progress = position of the slowest lane (DPP reduction, ~12 VALU), published every
         // iteration on a short ring and every other one where a stale value only delays slot
         // recycling by a step
-        if (!(it & Q.pmask)) {
+        if (!EARLY && !(it & Q.pmask)) {
           const int plo = wave_min_i32(pb);
           if (plo != pos) {  // positions below plo are done: their lower slices may be recycled
             pos = plo;       // (every slot read of earlier iterations has returned: slab_read8 waits)
@@ -681,7 +689,12 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
         }
         asm volatile("" ::: "memory");  // slot reads stay behind the poll
         bool d_hit = false;  // (diagnostic counters only)
-        if (act && !stream_only) {
+        // ---- part A: where the sample is and its corner addresses; EARLY: the whole corner batch
+        float fx = 0.f, fy = 0.f, fz = 0.f;
+        unsigned a0 = 0, b0 = 0;
+        typename std::conditional<DT == 0, v2u, v4f>::type rq[EARLY ? 8 : 1];
+        const bool work = act && !stream_only;
+        if (work) {
           // the two slices' slot images (one 8-byte table entry each, adjacent): issued first,
           // the position arithmetic below covers the LDS round trip
           const int *te = reinterpret_cast<const int *>(smem + (wtab_addr - ring_addr)) + 2 * (psgn * pb + eoff);
@@ -690,20 +703,60 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           const float p0 = __fmaf_rn(mf, B[0], A[0]), p1 = __fmaf_rn(mf, B[1], A[1]), p2 = __fmaf_rn(mf, B[2], A[2]);
           // (no membership test: [m, m1] is exactly the inside interval, see the set-up)
           int x0, x1, y0, y1, z0, z1;
-          float fx, fy, fz;
           smk_lin_clamp(p0, P.N[0], x0, x1, fx);
           smk_lin_clamp(p1, P.N[1], y0, y1, fy);
           smk_lin_clamp(p2, P.N[2], z0, z1, fz);
           const int iu = AU == 0 ? x0 : y0, iv = AV == 1 ? y0 : z0;  // global voxel indices
           const unsigned lo_off = __umul24((unsigned)iv, pitch_b) + ((unsigned)iu << VBL);  // (24-bit multiply: full rate)
-          const unsigned a0 = (unsigned)base_a + lo_off, b0 = (unsigned)base_b + lo_off;
+          a0 = (unsigned)base_a + lo_off;
+          b0 = (unsigned)base_b + lo_off;
+          if constexpr (EARLY) slab_read8_full(a0, a0 + pitch_b, b0, b0 + pitch_b, rq);
+        }
+        if constexpr (EARLY) {
+          // everything this iteration needs of the ring is in registers: release the slots NOW, not
+          // a classification + shading later -- on a 5-slot ring the loaders otherwise sit blocked
+          // for most of the consumers' iteration
+          int pbn = pb;
+          if (act) pbn = (m + 1 <= m1) ? psgn * base_slice(m + 1) + poff : SLAB_DONE;
+          const int plo = wave_min_i32(pbn);
+          if (plo != pos && plo < SLAB_DONE) {
+            pos = plo;
+            if (lane == 0) lds_st(&ctl[8 + wave], pos);
+          }
+        }
+        if (work) {
           // corners <ds><dv><du> -> model order <dx><dy><dz>; lerp order x, y, z like the gather kernel
 #define QI(dx, dy, dz) (PERM == 0 ? ((dz) * 4 + (dy) * 2 + (dx)) : PERM == 1 ? ((dy) * 4 + (dz) * 2 + (dx)) : ((dx) * 4 + (dz) * 2 + (dy)))
 #define TRI(E)                                                                                                             \
   smk_lerp(smk_lerp(smk_lerp(E(0, 0, 0), E(1, 0, 0), fx), smk_lerp(E(0, 1, 0), E(1, 1, 0), fx), fy),                       \
            smk_lerp(smk_lerp(E(0, 0, 1), E(1, 0, 1), fx), smk_lerp(E(0, 1, 1), E(1, 1, 1), fx), fy), fz)
           float ch0, ch1, ch2 = 0.f, ch3 = 0.f;
-          if constexpr (DT == 1) {
+          if constexpr (EARLY && DT == 1) {
+#define E0(dx, dy, dz) rq[QI(dx, dy, dz)].x
+#define E1(dx, dy, dz) rq[QI(dx, dy, dz)].y
+#define E2(dx, dy, dz) rq[QI(dx, dy, dz)].z
+            ch0 = TRI(E0);
+            ch1 = TRI(E1);
+            if (P.third_axis) ch2 = TRI(E2);
+#undef E2
+#undef E1
+#undef E0
+          } else if constexpr (EARLY && DT == 0) {
+#define E0(dx, dy, dz) smk_ub(rq[QI(dx, dy, dz)].x, 0)
+#define E1(dx, dy, dz) smk_ub(rq[QI(dx, dy, dz)].x, 1)
+#define E2(dx, dy, dz) smk_ub(rq[QI(dx, dy, dz)].x, 2)
+#define E3(dx, dy, dz) smk_ub(rq[QI(dx, dy, dz)].x, 3)
+            ch0 = TRI(E0) * SMK_INV255;
+            ch1 = TRI(E1) * SMK_INV255;
+            if (P.third_axis) {
+              ch2 = TRI(E2) * SMK_INV255;
+              if (P.nelts == 4) ch3 = TRI(E3) * SMK_INV255;
+            }
+#undef E3
+#undef E2
+#undef E1
+#undef E0
+          } else if constexpr (DT == 1) {
             if (P.third_axis) {
               v3f q[8];
               slab_read8(a0, a0 + pitch_b, b0, b0 + pitch_b, q);
@@ -781,8 +834,14 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             if (SH == 0) {
               src = smk_shade_sample<0>(P, col, 0.f, 0.f, 0.f, 0.f);
             } else {
-              uint32_t nb[8];  // second batch: the packed normals of the same corners
-              if (DT == 1) slab_read8_nb16(a0, a0 + pitch_b, b0, b0 + pitch_b, nb);
+              uint32_t nb[8];  // the packed normals of the same corners: second batch, or already here (EARLY)
+              if constexpr (EARLY) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                  if constexpr (DT == 1) nb[k] = __float_as_uint(rq[k].w);
+                  else nb[k] = rq[k].y;
+                }
+              } else if (DT == 1) slab_read8_nb16(a0, a0 + pitch_b, b0, b0 + pitch_b, nb);
               else slab_read8_nb8(a0, a0 + pitch_b, b0, b0 + pitch_b, nb);
 #define NB(dx, dy, dz) nb[QI(dx, dy, dz)]
               float n0 = smk_nrm(NB(0, 0, 0), NB(1, 0, 0), NB(0, 1, 0), NB(1, 1, 0), NB(0, 0, 1), NB(1, 0, 1), NB(0, 1, 1), NB(1, 1, 1), 0, fx, fy, fz);
