@@ -86,6 +86,9 @@ extern "C" void smk_destroy(smk_ctx *c) {
   if (c->slab.h_order) (void)hipHostFree(c->slab.h_order);
   if (c->slab.order_ev) (void)hipEventDestroy(c->slab.order_ev);
   if (c->slab.d_trace) (void)hipFree(c->slab.d_trace);
+  if (c->slab.d_ticks) (void)hipFree(c->slab.d_ticks);
+  if (c->slab.h_ticks) (void)hipHostFree(c->slab.h_ticks);
+  if (c->slab.ticks_ev) (void)hipEventDestroy(c->slab.ticks_ev);
   for (hipEvent_t e : c->tev0) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->tev1) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -69,7 +69,14 @@ struct SlabAux {
   hipEvent_t order_ev = nullptr;  // completion of the last staging -> device copy
   int order_cap = 0;
   std::vector<int> order_host;  // what d_order holds
-  unsigned *d_trace = nullptr;  // [trace_n][4] workgroup timeline of the last traced frame (option lockstep bit 32)
+  // per-tile workgroup durations of an earlier frame: the schedule's weights
+  unsigned *d_ticks = nullptr, *h_ticks = nullptr;  // device buffer the kernel writes; pinned copy in flight
+  int ticks_cap = 0, ticks_pending_n = 0;
+  bool ticks_pending = false;
+  long long ticks_pending_sig = 0, ticks_good_sig = -1;
+  hipEvent_t ticks_ev = nullptr;
+  std::vector<unsigned> ticks_good;
+  unsigned *d_trace = nullptr;  // [trace_n][8] workgroup timeline of the last traced frame (option lockstep bit 32)
   int trace_cap = 0, trace_n = 0;
 };
 

@@ -64,6 +64,7 @@ struct SlabParams {
   int use_occ;                 // (V,G) occupancy bitmap copied to LDS
   int fast_tf;                 // alpha-first classification with 8-byte texel loads (no third axis, or use_ah)
   const int *order;            // tile of each block (work-balanced schedule, -1 = none), see smk_launch_slab
+  unsigned *tile_ticks;        // [ntiles] duration of each tile's workgroup in 100 MHz ticks (next frame's weights)
   int *status;                 // host-visible word: 1 = protocol time-out, 2 = window bound violated
   float *diag;                 // [16] diagnostic counters (lockstep bit 16) or null
   unsigned *trace;             // [nblocks][8] per-workgroup timeline record (lockstep bit 32, see smk.h) or null
@@ -241,8 +242,9 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   const int tile = Q.order[blockIdx.x];
   if (tile < 0) return;  // whole workgroup leaves together
   const bool tracing = DIAG && Q.trace != nullptr && (P.lockstep & 32);  // (diagnostic: workgroup timeline)
-  unsigned trace_t0 = 0;
-  if (tracing) trace_t0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+  // the workgroup's duration feeds the next frame's schedule (see smk_launch_slab): one scalar
+  // timestamp at each end and one 4-byte store per tile
+  const unsigned trace_t0 = (unsigned)__builtin_amdgcn_s_memrealtime();
   const int ty = tile / P.ntx, tx = tile - ty * P.ntx;
 
   const int tid = threadIdx.x;
@@ -896,6 +898,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
     __syncthreads();
     if (tid == 0 && ctl[3]) *(volatile int *)Q.status = ctl[3];
   }
+  if (tid == 0 && Q.tile_ticks) Q.tile_ticks[tile] = max((unsigned)__builtin_amdgcn_s_memrealtime() - trace_t0, 1u);
   if (tracing && tid == 0) {
     unsigned *t = Q.trace + 8 * (size_t)blockIdx.x;
     t[0] = trace_t0;
@@ -1125,8 +1128,46 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     // stream about the same number of slices -- tiles at the image border cross less of the
     // volume than central ones -- and starts its long tiles first (shortest tail).
     int nblocks = 0;
+    long long ticks_sig_now = 0;
+    int ticks_n_now = 0;
     {
       const int nt = P.ntx * P.nty;
+      // measured weights: the previous frame's per-tile workgroup durations, when they are of this
+      // very tiling and marching direction.  (The geometric estimate above -- slices streamed --
+      // misses what consumers cost: on 1024^3 the XCDs holding the image's top and bottom rows ran
+      // 1.6x longer per slice than the central ones and the frame waited for them.)
+      const long long tsig = (((long long)P.ntx * 4096 + P.nty) * 64 + tw) * 64 + th + ((long long)(Q.perm * 2 + (Q.dir > 0)) << 48) +
+                             ((long long)nw << 52) + ((long long)dtype << 56);
+      if (aux->ticks_pending && hipEventQuery(aux->ticks_ev) == hipSuccess) {  // a copy has come back
+        aux->ticks_good.assign(aux->h_ticks, aux->h_ticks + aux->ticks_pending_n);
+        aux->ticks_good_sig = aux->ticks_pending_sig;
+        aux->ticks_pending = false;
+      }
+      (void)hipGetLastError();
+      if (aux->ticks_good_sig == tsig && (int)aux->ticks_good.size() == nt)
+        for (int t = 0; t < nt; ++t)
+          if (aux->ticks_good[t] > 0) work[t] = (int)std::min<unsigned>(aux->ticks_good[t], 1u << 30);
+      if (nt > aux->ticks_cap) {
+        if (aux->ticks_pending) (void)hipEventSynchronize(aux->ticks_ev);
+        aux->ticks_pending = false;
+        if (aux->d_ticks) (void)hipFree(aux->d_ticks);
+        if (aux->h_ticks) (void)hipHostFree(aux->h_ticks);
+        aux->d_ticks = nullptr;
+        aux->h_ticks = nullptr;
+        aux->ticks_cap = 0;
+        hipError_t e = hipMalloc((void **)&aux->d_ticks, (size_t)nt * 4);
+        if (e != hipSuccess) return e;
+        e = hipHostMalloc((void **)&aux->h_ticks, (size_t)nt * 4, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        aux->ticks_cap = nt;
+      }
+      if (!aux->ticks_ev) {
+        hipError_t e = hipEventCreateWithFlags(&aux->ticks_ev, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+      }
+      Q.tile_ticks = aux->d_ticks;
+      ticks_sig_now = tsig;
+      ticks_n_now = nt;
       long long total = 0;
       for (int t = 0; t < nt; ++t) total += work[t];
       std::vector<std::vector<int>> run(8);
@@ -1195,12 +1236,23 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     // developer diagnostics (option lockstep bits 2..64) live in separate instances of the f32 +
     // R8k kernels only: compiled into the product kernels they cost SGPRs (spills) in every frame
     const bool diag = (P.lockstep & ~1) != 0 && dtype == 1 && shade_kind == 1;
+    auto after_launch = [&](hipError_t e) -> hipError_t {
+      if (e != hipSuccess || aux->ticks_pending) return e;
+      // fetch this frame's per-tile durations (one copy in flight at a time)
+      hipError_t e2 = hipMemcpyAsync(aux->h_ticks, aux->d_ticks, (size_t)ticks_n_now * 4, hipMemcpyDeviceToHost, s);
+      if (e2 == hipSuccess) e2 = hipEventRecord(aux->ticks_ev, s);
+      if (e2 != hipSuccess) return e2;
+      aux->ticks_pending = true;
+      aux->ticks_pending_sig = ticks_sig_now;
+      aux->ticks_pending_n = ticks_n_now;
+      return hipSuccess;
+    };
 #define GO(D, S, R, N, L)                                                                              \
   if (dtype == D && shade_kind == S && Q.perm == R && nw == N && nl == L) {                          \
     if constexpr (D == 1 && S == 1) {                                                                \
-      if (diag) return launch_slab<D, S, R, N, L, true>(P, Q, lds, nblocks, s);                      \
+      if (diag) return after_launch(launch_slab<D, S, R, N, L, true>(P, Q, lds, nblocks, s));        \
     }                                                                                                \
-    return launch_slab<D, S, R, N, L, false>(P, Q, lds, nblocks, s);                                 \
+    return after_launch(launch_slab<D, S, R, N, L, false>(P, Q, lds, nblocks, s));                   \
   }
 #define GO_NW(D, S, R) GO(D, S, R, 4, 1) GO(D, S, R, 6, 2) GO(D, S, R, 8, 1) GO(D, S, R, 8, 2) GO(D, S, R, 8, 4) GO(D, S, R, 9, 2) GO(D, S, R, 12, 2) GO(D, S, R, 12, 4)
 #define GO_R(D, S) GO_NW(D, S, 0) GO_NW(D, S, 1) GO_NW(D, S, 2)
