@@ -160,7 +160,13 @@ def run_frames(r, nframes, frame, world, compositor_state):
                 frame.copy_(full[:frame.shape[0]])
 
 
-def timed(r, K, W, frame, world, cstate):
+SETTLE_FRAMES = 6   # untimed set-up before the warm-up: auto mode times both ray-marchers (4 frames)
+#                     and the tile schedule takes its weights from a measured frame
+
+
+def timed(r, K, W, frame, world, cstate, settle=True):
+    if settle:
+        run_frames(r, SETTLE_FRAMES, frame, world, cstate)
     run_frames(r, W, frame, world, cstate)
     if world > 1:
         dist.barrier()

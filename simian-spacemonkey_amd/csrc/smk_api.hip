@@ -83,8 +83,10 @@ extern "C" void smk_destroy(smk_ctx *c) {
   if (c->slab.h_status) (void)hipHostFree(c->slab.h_status);
   if (c->slab.d_diag) (void)hipFree(c->slab.d_diag);
   if (c->slab.d_order) (void)hipFree(c->slab.d_order);
-  if (c->slab.h_order) (void)hipHostFree(c->slab.h_order);
-  if (c->slab.order_ev) (void)hipEventDestroy(c->slab.order_ev);
+  for (int k = 0; k < 4; ++k) {
+    if (c->slab.h_order[k]) (void)hipHostFree(c->slab.h_order[k]);
+    if (c->slab.order_ev[k]) (void)hipEventDestroy(c->slab.order_ev[k]);
+  }
   if (c->slab.d_trace) (void)hipFree(c->slab.d_trace);
   if (c->slab.d_ticks) (void)hipFree(c->slab.d_ticks);
   if (c->slab.h_ticks) (void)hipHostFree(c->slab.h_ticks);
@@ -858,7 +860,8 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
   int slot = (int)(c->tcount % SMK_TIMING_RING);
   c->ev0 = c->tev0[slot];
   c->ev1 = c->tev1[slot];
-  HIPCHK(c, hipEventRecord(c->ev0, s));
+  // (ev0 is recorded by the launcher right before the kernel: host-side planning between the two
+  //  events would otherwise count as kernel time whenever the stream is idle)
   // kernel choice: the slice-ring kernel when it applies (2-D / separable classification,
   // no perturbation, rays sharing one principal axis), the generic gather kernel otherwise
   c->last_kernel = 1;
@@ -887,7 +890,7 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
         c->tune_sig = sig;
         c->tune_state = 0;
       }
-      if (c->tune_state == 2) {  // both trials issued: decide once their events have completed
+      if (c->tune_state == 4) {  // both timed trials issued: decide once their events have completed
         float ms_s = 0, ms_g = 0;
         if (hipEventQuery(c->tev1[c->tune_slot[0]]) == hipSuccess && hipEventQuery(c->tev1[c->tune_slot[1]]) == hipSuccess &&
             hipEventElapsedTime(&ms_s, c->tev0[c->tune_slot[0]], c->tev1[c->tune_slot[0]]) == hipSuccess &&
@@ -897,8 +900,8 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
         }  // else: keep the slice-ring kernel for this frame and ask again
         (void)hipGetLastError();
       } else {
-        trial = c->tune_state;
-        try_slab = trial == 0;
+        trial = c->tune_state;  // 0,1: untimed first launches (one-time set-up), 2,3: the timed pair
+        try_slab = (trial & 1) == 0;
       }
     }
   }
@@ -912,6 +915,7 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
     if (c->opt_lockstep & 16) HIPCHK(c, hipMemsetAsync(c->slab.d_diag, 0, 16 * sizeof(float), s));
     const char *why = nullptr;
     const int forced = c->opt_kernel == 2;
+    c->slab.frame_ev0 = c->ev0;
     hipError_t e = smk_launch_slab(P, c->dtype, shade_kind_of(c), c->opt_slab_T, c->opt_tile, forced, c->d_vox,
                                    c->d_vox_x, &c->slab, &why, s);
     if (e == hipErrorNotSupported && why && !strcmp(why, "x-major copy unavailable")) {
@@ -932,10 +936,13 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
   } else if (c->opt_kernel == 2) {
     FAIL(c, "smk_render: slab kernel forced but classification mode %d is gather-only", c->tf_mode);
   }
-  if (c->last_kernel == 1) HIPCHK(c, smk_launch_gather(P, c->dtype, c->tf_mode, shade_kind_of(c), s));
+  if (c->last_kernel == 1) {
+    HIPCHK(c, hipEventRecord(c->ev0, s));
+    HIPCHK(c, smk_launch_gather(P, c->dtype, c->tf_mode, shade_kind_of(c), s));
+  }
   HIPCHK(c, hipEventRecord(c->ev1, s));
   if (trial >= 0) {
-    c->tune_slot[trial] = slot;
+    if (trial >= 2) c->tune_slot[trial - 2] = slot;
     c->tune_state = trial + 1;
   }
   c->tcount++;

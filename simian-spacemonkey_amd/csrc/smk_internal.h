@@ -63,15 +63,17 @@ struct RenderParams {
 // side buffers of the slice-ring kernel, owned by the context
 struct SlabAux {
   int *h_status = nullptr;      // pinned, device-visible: error word (0 = ok)
+  hipEvent_t frame_ev0 = nullptr;  // recorded by the launcher right before its first stream operation
   float *d_diag = nullptr;      // [16] diagnostic counters (option lockstep bit 16)
   int *d_order = nullptr;       // tile schedule of the current camera
-  int *h_order = nullptr;       // its pinned staging copy
-  hipEvent_t order_ev = nullptr;  // completion of the last staging -> device copy
+  int *h_order[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned staging copies, used in turn
+  hipEvent_t order_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // completion of each one's last copy
+  int order_next = 0;
   int order_cap = 0;
   std::vector<int> order_host;  // what d_order holds
   // per-tile workgroup durations of an earlier frame: the schedule's weights
   unsigned *d_ticks = nullptr, *h_ticks = nullptr;  // device buffer the kernel writes; pinned copy in flight
-  int ticks_cap = 0, ticks_pending_n = 0;
+  int ticks_cap = 0, ticks_pending_n = 0, ticks_age = 0;
   bool ticks_pending = false;
   long long ticks_pending_sig = 0, ticks_good_sig = -1;
   hipEvent_t ticks_ev = nullptr;

@@ -1138,9 +1138,15 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
       // 1.6x longer per slice than the central ones and the frame waited for them.)
       const long long tsig = (((long long)P.ntx * 4096 + P.nty) * 64 + tw) * 64 + th + ((long long)(Q.perm * 2 + (Q.dir > 0)) << 48) +
                              ((long long)nw << 52) + ((long long)dtype << 56);
+      ++aux->ticks_age;
       if (aux->ticks_pending && hipEventQuery(aux->ticks_ev) == hipSuccess) {  // a copy has come back
-        aux->ticks_good.assign(aux->h_ticks, aux->h_ticks + aux->ticks_pending_n);
-        aux->ticks_good_sig = aux->ticks_pending_sig;
+        // (adopted at once for a new tiling, then every 32 frames: durations of a steady view barely
+        //  move, and every new table is an upload and a host touch of the launch stream)
+        if (aux->ticks_good_sig != aux->ticks_pending_sig || aux->ticks_age >= 32) {
+          aux->ticks_good.assign(aux->h_ticks, aux->h_ticks + aux->ticks_pending_n);
+          aux->ticks_good_sig = aux->ticks_pending_sig;
+          aux->ticks_age = 0;
+        }
         aux->ticks_pending = false;
       }
       (void)hipGetLastError();
@@ -1186,33 +1192,45 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
       std::vector<int> order((size_t)nblocks, -1);
       for (int x = 0; x < 8; ++x)
         for (size_t k = 0; k < run[x].size(); ++k) order[k * 8 + x] = run[x][k];
+      if (aux->frame_ev0) {  // the frame's kernel-time bracket opens here: planning is done
+        hipError_t e = hipEventRecord(aux->frame_ev0, s);
+        if (e != hipSuccess) return e;
+      }
       if (aux->order_host != order) {  // unchanged camera: the table on the device is still right
         if ((int)order.size() > aux->order_cap) {
           if (aux->d_order) (void)hipFree(aux->d_order);
-          if (aux->h_order) (void)hipHostFree(aux->h_order);
           aux->d_order = nullptr;
-          aux->h_order = nullptr;
+          for (int k = 0; k < 4; ++k) {
+            if (aux->order_ev[k]) (void)hipEventSynchronize(aux->order_ev[k]);
+            if (aux->h_order[k]) (void)hipHostFree(aux->h_order[k]);
+            aux->h_order[k] = nullptr;
+          }
           aux->order_cap = 0;
           hipError_t e = hipMalloc((void **)&aux->d_order, order.size() * sizeof(int));
           if (e != hipSuccess) return e;
-          e = hipHostMalloc((void **)&aux->h_order, order.size() * sizeof(int), hipHostMallocDefault);
-          if (e != hipSuccess) return e;
+          for (int k = 0; k < 4; ++k) {
+            e = hipHostMalloc((void **)&aux->h_order[k], order.size() * sizeof(int), hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+          }
           aux->order_cap = (int)order.size();
         }
         // pinned staging + a copy ON THE LAUNCH STREAM: a copy from pageable memory is not
         // stream-ordered against the kernel that follows (seen as wrong tiles when several
-        // contexts render at once).  The staging buffer is rewritten only after its last copy.
-        if (!aux->order_ev) {
-          hipError_t e = hipEventCreateWithFlags(&aux->order_ev, hipEventDisableTiming);
+        // contexts render at once).  Four staging buffers in turn, each rewritten only after its
+        // own last copy: the host does not wait for the stream unless it is four tables ahead.
+        const int k = aux->order_next;
+        aux->order_next = (k + 1) & 3;
+        if (!aux->order_ev[k]) {
+          hipError_t e = hipEventCreateWithFlags(&aux->order_ev[k], hipEventDisableTiming);
           if (e != hipSuccess) return e;
         } else {
-          hipError_t e = hipEventSynchronize(aux->order_ev);
+          hipError_t e = hipEventSynchronize(aux->order_ev[k]);
           if (e != hipSuccess) return e;
         }
-        memcpy(aux->h_order, order.data(), order.size() * sizeof(int));
-        hipError_t e = hipMemcpyAsync(aux->d_order, aux->h_order, order.size() * sizeof(int), hipMemcpyHostToDevice, s);
+        memcpy(aux->h_order[k], order.data(), order.size() * sizeof(int));
+        hipError_t e = hipMemcpyAsync(aux->d_order, aux->h_order[k], order.size() * sizeof(int), hipMemcpyHostToDevice, s);
         if (e != hipSuccess) return e;
-        e = hipEventRecord(aux->order_ev, s);
+        e = hipEventRecord(aux->order_ev[k], s);
         if (e != hipSuccess) return e;
         aux->order_host.swap(order);
       }
