@@ -684,10 +684,10 @@ static int check_slab_status(smk_ctx *c) {
 extern "C" int smk_get_stat(smk_ctx *c, const char *name, double *value) {
   if (!c || !name || !value) return 1;
   HIPCHK(c, hipSetDevice(c->device));
-  static const char *diag_names[12] = {"slab_iters", "slab_active_lanes", "slab_inside_lanes", "slab_hit_lanes",
+  static const char *diag_names[14] = {"slab_iters", "slab_active_lanes", "slab_inside_lanes", "slab_hit_lanes",
                                       "slab_loader_issue_kcyc", "slab_loader_wait_kcyc", "slab_loader_blocked_kcyc", "slab_loader_total_kcyc",
-                                      "slab_iters_with_hit", "slab_lead_sum", "slab_waits", "slab_wstep_sum"};
-  for (int k = 0; k < 12; ++k)
+                                      "slab_iters_with_hit", "slab_lead_sum", "slab_waits", "slab_wstep_sum", "slab_dead_tail_sum", "slab_waves"};
+  for (int k = 0; k < 14; ++k)
     if (!strcmp(name, diag_names[k])) {
       float v = 0.f;
       if (c->slab.d_diag) {

@@ -128,7 +128,7 @@ struct SlabEnt {
   int base;      // LDS byte address of GLOBAL voxel (u=0, v=0) of this slice's slot image:
                  // corner address = base + v * pitch_bytes + u * voxel_bytes
   unsigned pack;  // loader: window origin u0 | v0 << 11 (stored-box voxels), (units the slice needs - 1) << 22,
-                  // min(15, wv - rows the slice needs) << 28
+                  // rows of the window the slice can spare, in sixteenths of wv, << 28
 };
 
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
@@ -228,6 +228,10 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   constexpr int NTH = (NW + NL) * 64;
   // big workgroups (one per CU, 128 VGPRs each): read whole voxels, release ring slots early
   constexpr bool EARLY = (NW + NL) > 10;
+  // ... and their loaders skip the row groups a slice does not need, counting DMA instructions per
+  // slice; small workgroups keep every slice the same number of instructions (cheaper bookkeeping:
+  // measured 3 % on the 512^3 frame, where the loaders' issue slots are the consumers')
+  constexpr bool FIFO = EARLY;
   extern __shared__ __align__(16) unsigned char smem[];
   // LDS carve: ring [nslots][slot_bytes] | slice table [Ds] | control words | alpha_H
   SlabEnt *wtab = reinterpret_cast<SlabEnt *>(smem + (size_t)Q.nslots * Q.slot_bytes);
@@ -423,7 +427,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       const int need_u = max((u1 - wu0 + UPV) / UPV, 1), need_v = max(v1 - wv0 + 1, 1);
       SlabEnt ent;
       ent.pack = (unsigned)wu0 | ((unsigned)wv0 << 11) | ((unsigned)(min(need_u, Q.wu) - 1) << 22) |
-                 ((unsigned)min(15, max(Q.wv - need_v, 0)) << 28);
+                 ((unsigned)min(15, max(Q.wv - need_v, 0) / ((Q.wv + 15) / 16)) << 28);  // rows spared, in 1/16ths of wv (rounded down)
       ent.base = (int)ring_addr + (q % nslots) * Q.slot_bytes - (Q.Ov + wv0) * (int)pitch_b - (Q.Ou + wu0) * VB;
       wtab[e] = ent;
     }
@@ -459,7 +463,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       // row groups g = lid, lid+NL, ... of every slice are mine; a group is `per` chunks = `rpg` rows
       const int per = Q.per, rpg = Q.rpg, groups = Q.groups;
       const int mygroups = (groups - lid + NL - 1) / NL;
-      const int mych = mygroups * per;  // DMA instructions THIS loader issues per slice
+      const int mych = mygroups * per;  // DMA wave-instructions of a whole window (this loader's share)
       const unsigned strideVb = (unsigned)(Q.strideV * (long long)sizeof(Vox));  // bytes, < 2^32
       // unit 64*k + lane of a group sits at (row, column) = divmod(64*k + lane, wp): fixed per lane and phase k
       unsigned voff[7], rowk[7], colk[7];
@@ -473,7 +477,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       const size_t gstep = (size_t)(NL * rpg) * strideVb;  // source advance from one of my groups to the next
       const size_t strideSb = (size_t)Q.strideS * sizeof(Vox);
       const bool l2hot = DIAG && (P.lockstep & 8) != 0;           // (diagnostic: every slice re-reads one slice)
-      int q = 0, inflight = 0, landed = 0, idle = 0, minp = 0, slot_q = 0;
+      int q = 0, inflight = 0, landed = 0, idle = 0, minp = 0, slot_q = 0, fly_total = 0;
+      int fly_counts = 0;  // lane (q & 63): DMA wave-instructions of load index q (a scalar array in one VGPR)
       if (DIAG && (P.lockstep & 64)) minp = 0x3ffffff0;  // (diagnostic: free-running stream, nobody consumes)
       // progress words, read by lane 0 alone (NW <= 16 words as four b128 reads)
       auto poll_progress = [&]() -> int {
@@ -520,13 +525,14 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             if (ql <= npos && e >= 0 && e < Q.Ds) ent_uv = (int)raw_lds_b64(&wtab[e]).y;  // (.pack; never -1: u0 < 2^11)
           }
           const int uv = __builtin_amdgcn_readlane(ent_uv, q & 63);
+          int issued = 0;  // DMA wave-instructions of this slice (this loader's share)
           const unsigned dst0 = ring_addr + (unsigned)(slot_q * Q.slot_bytes + lid * per * 1024);
           if (uv != -1) {
             const int sl = (dir > 0 ? smin + q : smax + 1 - q) - Q.Os;
             const unsigned u0 = (unsigned)uv & 0x7ffu, v0 = ((unsigned)uv >> 11) & 0x7ffu;
             // (small windows: the whole shape -- the saving would not pay for the partial-group path)
             const unsigned need_u = Q.mask_need ? (((unsigned)uv >> 22) & 0x3fu) + 1u : (unsigned)Q.wu;
-            const unsigned need_v = Q.mask_need ? (unsigned)Q.wv - ((unsigned)uv >> 28) : (unsigned)Q.wv;
+            const unsigned need_v = Q.mask_need ? (unsigned)Q.wv - ((unsigned)uv >> 28) * (unsigned)((Q.wv + 15) / 16) : (unsigned)Q.wv;
             const char *src = gv + (l2hot ? (size_t)0 : (size_t)sl * strideSb) + ((size_t)v0 * strideVb + (size_t)u0 * VB) +  // (64-bit: v0 * strideVb passes 4 GiB when V is the slowest axis of a 1024^3 volume)
                               (size_t)(lid * rpg) * strideVb;
             unsigned dst = dst0, row0 = (unsigned)(lid * rpg);
@@ -542,13 +548,18 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   }
             // Lanes outside what THIS slice needs of the window stay idle (the fixed shape is sized
             // for the widest section of the bundle; at a voxel per pixel the mean need is ~70 % of
-            // it).  Column masks are per slice; only a group that the needed rows end in pays a
-            // per-lane row test, and there lane 0 always loads so that every slice is the same
-            // number of wave-instructions (the in-order vmcnt counts slices).
+            // it).  Column masks are per slice; groups past the needed rows are not issued at all;
+            // only the group the needed rows end in pays a per-lane row test (lane 0 always loads
+            // there, so that a group is `per` wave-instructions: the in-order vmcnt counts slices
+            // through the per-slice instruction counts kept in fly_counts).
             bool cm[7];
 #pragma unroll
             for (int k = 0; k < 7; ++k) cm[k] = k < per && colk[k] < need_u;
             for (int g = 0; g < mygroups; ++g) {
+              if (FIFO) {
+                if (row0 >= need_v) break;  // nothing of this group (or the following ones) is needed: not issued, not counted
+                issued += per;
+              }
               if (row0 + (unsigned)rpg <= need_v) {
 #define SLAB_CHUNK_ROWS_OK(k) \
   if (cm[k]) SLAB_DMA(src, dst + k * 1024u, voff[k]);
@@ -569,13 +580,17 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
               row0 += (unsigned)(NL * rpg);
             }
 #undef SLAB_GROUP
-          } else {
-            // slice outside the stored box (never read): keep the instruction count uniform
+          } else if (!FIFO) {
+            // slice outside the stored box (never read): uniform counting wants its instructions all the same
             unsigned dst = dst0;
             for (int c = 0; c < mych; ++c) {
               SLAB_DMA(gv, dst, voff[0] * 0u);
               dst += 1024u;
             }
+          }
+          if (FIFO) {  // big windows: slices differ in what they issue, the counts are kept per slice
+            fly_counts = lane == (q & 63) ? issued : fly_counts;
+            fly_total += issued;
           }
           ++q;
           ++inflight;
@@ -588,8 +603,13 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
         }
         if (stop) break;
         if (inflight > 0) {
-          // retire the oldest slice in flight: all but the (inflight-1) younger slices' DMAs done
-          wait_vmcnt(mych * (inflight - 1));
+          // retire the oldest slice in flight: everything but the younger slices' DMAs is done
+          if (FIFO) {
+            fly_total -= __builtin_amdgcn_readlane(fly_counts, (q - inflight) & 63);
+            wait_vmcnt(fly_total);
+          } else {
+            wait_vmcnt(mych * (inflight - 1));  // small windows: every slice is mych wave-instructions
+          }
           --inflight;
           ++landed;
           raw_lds_st_b32(&ctl[4 + lid], landed);
@@ -886,6 +906,9 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
         atomicAdd(&Q.diag[9], n_lead);
         atomicAdd(&Q.diag[10], n_waits);
         atomicAdd(&Q.diag[11], n_wstep);
+        // (how much of the tile's slice range this wave did not need: it finished at position `pos`)
+        atomicAdd(&Q.diag[12], (float)max(npos - min(pos, npos), 0) / (float)max(npos, 1));
+        atomicAdd(&Q.diag[13], 1.0f);
       }
     }
   }

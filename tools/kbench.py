@@ -73,6 +73,8 @@ def main():
                    100 * r.stat("slab_iters_with_hit") / (it + 1e-9)), flush=True)
             print("   mean (landed - slowest lane) at step time %.2f slices; waits %.3g; mean wstep %.2f" %
                   (r.stat("slab_lead_sum") / (it + 1e-9), r.stat("slab_waits"), r.stat("slab_wstep_sum") / (it + 1e-9)), flush=True)
+            print("   mean share of its tile's slice range a wave no longer needs when it finishes: %.1f%%" %
+                  (100 * r.stat("slab_dead_tail_sum") / (r.stat("slab_waves") + 1e-9)), flush=True)
             li, lw, lb, lt = (r.stat(k) for k in ("slab_loader_issue_kcyc", "slab_loader_wait_kcyc", "slab_loader_blocked_kcyc", "slab_loader_total_kcyc"))
             print("   loader 0 of every workgroup, sum of kilo-cycles: issue(+poll) %.4g  vmcnt wait %.4g  ring-blocked %.4g  total %.4g  (= %.3f ms per CU at 2.4 GHz if spread over 256 CUs)" %
                   (li, lw, lb, lt, lt * 1e3 / 256 / 2.4e9 * 1e3), flush=True)
