@@ -73,7 +73,7 @@ struct SlabAux {
   std::vector<int> order_host;  // what d_order holds
   // per-tile workgroup durations of an earlier frame: the schedule's weights
   unsigned *d_ticks = nullptr, *h_ticks = nullptr;  // device buffer the kernel writes; pinned copy in flight
-  int ticks_cap = 0, ticks_pending_n = 0, ticks_age = 0;
+  int ticks_cap = 0, ticks_pending_n = 0, ticks_age = 0, ticks_adopted = 0;
   bool ticks_pending = false;
   long long ticks_pending_sig = 0, ticks_good_sig = -1;
   hipEvent_t ticks_ev = nullptr;

@@ -1163,10 +1163,20 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
                              ((long long)nw << 52) + ((long long)dtype << 56);
       ++aux->ticks_age;
       if (aux->ticks_pending && hipEventQuery(aux->ticks_ev) == hipSuccess) {  // a copy has come back
-        // (adopted at once for a new tiling, then every 32 frames: durations of a steady view barely
-        //  move, and every new table is an upload and a host touch of the launch stream)
-        if (aux->ticks_good_sig != aux->ticks_pending_sig || aux->ticks_age >= 32) {
-          aux->ticks_good.assign(aux->h_ticks, aux->h_ticks + aux->ticks_pending_n);
+        // (adopted at once for a new tiling, refined after 4, 8 and 16 frames -- a new order changes
+        //  who runs beside whom and with it the durations -- then every 32 frames: durations of a
+        //  steady view barely move, and every new table is an upload and a host touch of the stream)
+        const bool fresh = aux->ticks_good_sig != aux->ticks_pending_sig;
+        const int due = aux->ticks_adopted < 3 ? (4 << aux->ticks_adopted) : 32;
+        if (fresh || aux->ticks_age >= due) {
+          if (fresh || (int)aux->ticks_good.size() != aux->ticks_pending_n) {
+            aux->ticks_good.assign(aux->h_ticks, aux->h_ticks + aux->ticks_pending_n);
+            aux->ticks_adopted = 0;
+          } else {
+            for (int t = 0; t < aux->ticks_pending_n; ++t)  // damped: half the old weight, half the new measurement
+              aux->ticks_good[t] = (aux->ticks_good[t] + aux->h_ticks[t] + 1) / 2;
+            ++aux->ticks_adopted;
+          }
           aux->ticks_good_sig = aux->ticks_pending_sig;
           aux->ticks_age = 0;
         }
