@@ -140,24 +140,16 @@ def configure(r, workload, n, size, planes):
     return xform, mv
 
 
-def run_frames(r, nframes, frame, world, compositor_state):
+def run_frames(r, nframes, frame, world, pipeline):
     """nframes frames back to back; returns nothing (caller brackets with barrier+sync)"""
     for _ in range(nframes):
         if world == 1:
             r.render_device(frame.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
         else:
-            pkg, partial, order, tile_out = compositor_state
-            stream = torch.cuda.current_stream().cuda_stream
-            r.render_device(partial.data_ptr(), None, stream)
-
-            def comp(layers, order_):
-                r.composite_over_device(layers.data_ptr(), world, order_, layers.shape[1],
-                                        tile_out.data_ptr(), stream)
-                return tile_out
-            tile = pkg.sortlast.exchange_and_composite(partial, order, comp)
-            full = pkg.sortlast.gather_frame(tile, 0)
-            if full is not None:
-                frame.copy_(full[:frame.shape[0]])
+            pipe, order = pipeline
+            pipe.frame(frame, order)
+    if world > 1:
+        pipeline[0].drain()
 
 
 SETTLE_FRAMES = 6   # untimed set-up before the warm-up: auto mode times both ray-marchers (4 frames)
@@ -237,10 +229,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # SMK_BENCH_REHEARSE=1: developer rehearsal of the N>1 plumbing on a one-GPU box -- every rank
+    # uses cuda:0 and the layers travel over gloo through host memory (never a benchmark number)
+    rehearse = world > 1 and os.environ.get("SMK_BENCH_REHEARSE") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            local = 0
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if world != a.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
 
@@ -263,12 +262,13 @@ def main():
     frame = torch.zeros((npix, 4), dtype=torch.float32, device="cuda")
     cstate = None
     if world > 1:
-        tp = sortlast.tile_pixels(npix, world)
-        partial = torch.zeros((tp * world, 4), dtype=torch.float32, device="cuda")
-        tile_out = torch.zeros((tp, 4), dtype=torch.float32, device="cuda")
-        order = r.shard_order(world)
-        cstate = (pkg, partial, order, tile_out)
-        if world > 1 and rank != 0:
+        def march(ptr, stream):
+            r.render_device(ptr, None, stream)
+
+        def over(layers, order_, out_tile, stream):
+            r.composite_over_device(layers.data_ptr(), world, order_, layers.shape[1], out_tile.data_ptr(), stream)
+        cstate = (sortlast.Pipeline(march, over, npix, via_host=rehearse), r.shard_order(world))
+        if rank != 0:
             del vghf, nrm
             vghf = nrm = None
 
@@ -292,7 +292,8 @@ def main():
         "config": {"workload": "cfg3: %d^3 f32 VGH + u8 normals, 2-D LevWidget TF, R8k Phong (diff+spec), "
                                "%dx%d viewport x %d planes, pose 30deg about (1,1,0)" % (n, size, size, planes),
                    "volume": n, "viewport": size, "planes": planes,
-                   "parallelism": "sort-last x%d (brick shards, RCCL all-to-all + ordered over)" % world
+                   "parallelism": "sort-last x%d (brick shards; RCCL all-to-all + ordered over + gather, two "
+                                  "frames in flight: frame i's exchange overlaps frame i+1's ray-marching)" % world
                    if world > 1 else "single GPU",
                    "kernel": {1: "gather", 2: "slab-staged"}.get(kernel, str(kernel))},
     }
@@ -305,6 +306,23 @@ def main():
                            "algorithmic_bytes_per_launch": alg_bytes,
                            "note": "this rank's shard; %d^3 f32 working set is VALU/LDS-bound by "
                                    "construction (BASELINE.md sec. 2), see north_star" % n}
+    if rehearse:
+        out["data"] = "synthetic; REHEARSAL (all ranks on cuda:0, gloo through host memory): not a benchmark number"
+    if world > 1:
+        # outside the timed region: the merged frame against the same frame ray-marched unsharded
+        dist.barrier()
+        if rank == 0:
+            torch.cuda.synchronize()
+            merged = frame.clone()
+            whole = pkg.Renderer(dev)      # a second context holding the unsharded volume
+            whole.upload_volume_device(vghf.data_ptr(), (n, n, n), 3, 1, nrm.data_ptr())
+            configure(whole, "cfg3", n, size, planes)
+            whole.render_device(frame.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            whole.close()
+            out["sortlast_check"] = {"max_abs_err_vs_unsharded_frame": float((merged - frame).abs().max().item()),
+                                     "alpha_mean": float(merged[:, 3].mean().item()), "tolerance": 2e-5}
+        dist.barrier()
     if rank == 0 and world == 1 and not a.no_cpu:
         torch.cuda.synchronize()
         gpu_frame = frame.view(size, size, 4).cpu().numpy()

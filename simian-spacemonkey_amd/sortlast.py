@@ -55,23 +55,88 @@ def tile_pixels(npix, nranks):
     return (npix + nranks - 1) // nranks
 
 
-def exchange_and_composite(partial, order, compositor, group=None):
+def exchange_and_composite(partial, order, compositor, group=None, recv=None, via_host=False):
     """partial: [npix_padded, 4] premultiplied RGBA of THIS rank's shard (npix_padded divisible
-    by the world size).  Returns this rank's finished tile [npix_padded/P, 4]."""
+    by the world size).  Returns this rank's finished tile [npix_padded/P, 4].  `recv` lets a
+    caller keep one receive buffer per frame slot; `via_host` stages device tensors through host
+    memory for a backend that only moves CPU tensors (gloo rehearsals of the GPU plumbing)."""
     P = dist.get_world_size(group)
     n = partial.shape[0]
     assert n % P == 0
-    recv = torch.empty_like(partial)
     # direct send: piece r of my partial image goes to rank r; I receive piece `me` of everyone
-    dist.all_to_all_single(recv, partial, group=group)
+    if via_host and partial.is_cuda:
+        send = partial.cpu()
+        got = torch.empty_like(send)
+        dist.all_to_all_single(got, send, group=group)
+        recv = got.to(partial.device)
+    else:
+        if recv is None:
+            recv = torch.empty_like(partial)
+        dist.all_to_all_single(recv, partial, group=group)
     layers = recv.view(P, n // P, 4)
     return compositor(layers, order)
 
 
-def gather_frame(tile, dst=0, group=None):
+def gather_frame(tile, dst=0, group=None, via_host=False):
     """finished tiles -> full frame on rank dst ([npix_padded,4]); None elsewhere"""
     P = dist.get_world_size(group)
     me = dist.get_rank(group)
-    out = [torch.empty_like(tile) for _ in range(P)] if me == dst else None
-    dist.gather(tile, out, dst=dst, group=group)
-    return torch.cat(out, 0) if me == dst else None
+    src = tile.cpu() if via_host and tile.is_cuda else tile
+    out = [torch.empty_like(src) for _ in range(P)] if me == dst else None
+    dist.gather(src, out, dst=dst, group=group)
+    return torch.cat(out, 0).to(tile.device) if me == dst else None
+
+
+class Pipeline:
+    """Frames back to back with two in flight: while frame i's layers cross xGMI and are merged,
+    frame i+1 is already ray-marching.  Each slot has its own stream and buffers; the renderer
+    context itself is used by one frame at a time (frame i+1's launch waits for frame i's
+    ray-marcher, not for its exchange).  `render(ptr, stream_handle)` ray-marches this rank's
+    shard into the [npix_padded,4] buffer at `ptr`; `compositor(layers, order, out, stream_handle)`
+    merges [P, tile, 4] front to back into `out`."""
+
+    def __init__(self, render, compositor, npix, group=None, slots=2, via_host=False):
+        self.render, self.compositor, self.group, self.via_host = render, compositor, group, via_host
+        P = dist.get_world_size(group)
+        tp = tile_pixels(npix, P)
+        self.npix = npix
+        self.slots = []
+        for _ in range(slots):
+            self.slots.append({
+                "stream": torch.cuda.Stream(),
+                "partial": torch.zeros((tp * P, 4), dtype=torch.float32, device="cuda"),
+                "recv": torch.empty((tp * P, 4), dtype=torch.float32, device="cuda"),
+                "tile": torch.zeros((tp, 4), dtype=torch.float32, device="cuda")})
+        self.count = 0
+        self.marched = None      # event: the latest frame's ray-marcher has finished
+        self.delivered = None    # event: the latest frame has been copied into the caller's buffer
+
+    def frame(self, out, order):
+        """enqueue one frame; on rank 0 `out` ([npix,4]) receives it.  Returns at once."""
+        sl = self.slots[self.count % len(self.slots)]
+        self.count += 1
+        s = sl["stream"]
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            if self.marched is not None:
+                s.wait_event(self.marched)
+            self.render(sl["partial"].data_ptr(), s.cuda_stream)
+            self.marched = torch.cuda.Event()
+            self.marched.record(s)
+
+            def comp(layers, order_):
+                self.compositor(layers, order_, sl["tile"], s.cuda_stream)
+                return sl["tile"]
+            tile = exchange_and_composite(sl["partial"], order, comp, self.group, sl["recv"], self.via_host)
+            full = gather_frame(tile, 0, self.group, self.via_host)
+            if full is not None:
+                if self.delivered is not None:
+                    s.wait_event(self.delivered)
+                out.copy_(full[:self.npix])
+                self.delivered = torch.cuda.Event()
+                self.delivered.record(s)
+
+    def drain(self):
+        """make the caller's current stream wait for every frame enqueued so far"""
+        for sl in self.slots:
+            torch.cuda.current_stream().wait_stream(sl["stream"])

@@ -70,3 +70,25 @@ def test_perturbation_needs_halo_when_sharded(gpu_renderer_factory, smk):
         assert np.abs(R.render() - sc.render()).max() <= 1e-4
     finally:
         R.close()
+
+
+def test_bench_multi_rank_plumbing_rehearsal():
+    """bench.py's N>1 path (shards, two frames in flight, exchange, ordered over, gather) run as
+    two ranks that share this one GPU, the layers travelling over gloo through host memory: the
+    merged frame must equal the unsharded frame bench.py renders beside it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMK_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+           "--gpus", "2", "--steps", "3", "--warmup", "1", "--volume", "96", "--size", "192", "--planes", "96"]
+    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and "REHEARSAL" in out["data"]
+    assert out["sortlast_check"]["alpha_mean"] > 0.01
+    assert out["sortlast_check"]["max_abs_err_vs_unsharded_frame"] <= 2e-5
