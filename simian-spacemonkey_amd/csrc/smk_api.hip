@@ -198,9 +198,22 @@ static int upload_impl(smk_ctx *c, const smk_volume_desc *b, int nb, int nelts, 
     c->O[a] = lo;
     c->D[a] = hi - lo;
   }
+  // 8-byte voxels travel to LDS in 16-byte units: the slice-ring kernel wants even row lengths
+  // along both axes that can be its contiguous one (x, and y in the x-major copy) -- one more halo
+  // voxel where the volume has one, else a pad column nobody samples (index N: the texel pair of a
+  // clamped coordinate ends at N-1)
+  bool padded = false;
+  if (dtype == SMK_U8)
+    for (int a = 0; a < 2; ++a)
+      if (c->D[a] & 1) {
+        if (c->O[a] + c->D[a] < N[a]) ++c->D[a];
+        else if (c->O[a] > 0) { --c->O[a]; ++c->D[a]; }
+        else { ++c->D[a]; padded = true; }
+      }
   size_t nst = (size_t)c->D[0] * c->D[1] * c->D[2];
   size_t vb = dtype == SMK_U8 ? 8 : 16;
   HIPCHK(c, hipMalloc(&c->d_vox, nst * vb));
+  if (padded) HIPCHK(c, hipMemset(c->d_vox, 0, nst * vb));
   c->vox_bytes = nst * vb;
   bool n_in_w = dtype == SMK_F32 && nelts <= 3;
   if (dtype == SMK_F32 && nelts == 4 && any_grad) HIPCHK(c, hipMalloc((void **)&c->d_nrm, nst * 4));

@@ -942,6 +942,117 @@ static void host_ray(const RenderParams &P, int i, int j, double A[3], double B[
   }
 }
 
+// ---- S-extent of (a tile's ray bundle between the first and the last sample plane) /\ (the region
+// box), in voxel index coordinates.  The bundle is the pyramid section spanned by the rays through
+// the tile's outer pixel EDGES (half a pixel beyond the corner pixels' centres, so a one-pixel-wide
+// tile is not degenerate); rays are affine in the pixel coordinate, so every ray of the tile lies
+// inside it.  Both bodies are convex: the extrema over the intersection sit on its vertices = the
+// vertices of the box faces clipped by the pyramid's six planes + the pyramid's corners inside the
+// box.  Corner rays alone do not bound this: all four may miss a volume that projects inside the
+// tile, and a ray through a side face enters anywhere between the front and the back face.
+namespace {
+struct SlabVec { double v[3]; };
+
+int slab_clip_polygon(const SlabVec *in, int n, const double pl[4], SlabVec *out) {  // keeps pl.(p,1) >= 0
+  int m = 0;
+  for (int k = 0; k < n; ++k) {
+    const SlabVec &a = in[k], &b = in[(k + 1) % n];
+    const double da = pl[0] * a.v[0] + pl[1] * a.v[1] + pl[2] * a.v[2] + pl[3];
+    const double db = pl[0] * b.v[0] + pl[1] * b.v[1] + pl[2] * b.v[2] + pl[3];
+    if (da >= 0) out[m++] = a;
+    if ((da >= 0) != (db >= 0)) {
+      const double t = da / (da - db);
+      SlabVec c;
+      for (int i = 0; i < 3; ++i) c.v[i] = a.v[i] + t * (b.v[i] - a.v[i]);
+      out[m++] = c;
+    }
+  }
+  return m;
+}
+
+bool slab_bundle_slice_range(const RenderParams &P, double fx0, double fy0, double fx1, double fy1, int as, double *smin,
+                             double *smax) {
+  const smk_raycoef &rc = P.rc;
+  const double fx[4] = {fx0, fx1, fx1, fx0}, fy[4] = {fy0, fy0, fy1, fy1};  // cyclic
+  const double q0 = -0.5, q1 = (double)(rc.nplanes - 1) + 0.5;
+  SlabVec F[4][2];
+  double cen[3] = {0, 0, 0}, scale = 1.0;
+  for (int c = 0; c < 4; ++c) {
+    const double px = fx[c] * (double)rc.pxs + (double)rc.pxl, py = fy[c] * (double)rc.pys + (double)rc.pyl;
+    for (int a = 0; a < 3; ++a) {
+      const double A = px * rc.Ax[a] + py * rc.Ay[a] + rc.Ac[a], B = px * rc.Bx[a] + py * rc.By[a] + rc.Bc[a];
+      F[c][0].v[a] = A + q0 * B;
+      F[c][1].v[a] = A + q1 * B;
+      cen[a] += (F[c][0].v[a] + F[c][1].v[a]) / 8.0;
+      scale = std::max(scale, std::max(fabs(F[c][0].v[a]), fabs(F[c][1].v[a])));
+    }
+  }
+  double planes[6][4];
+  int npl = 0;
+  auto add_plane = [&](const SlabVec &a, const SlabVec &b, const SlabVec &c) {
+    double e1[3], e2[3], n[4];
+    for (int i = 0; i < 3; ++i) { e1[i] = b.v[i] - a.v[i]; e2[i] = c.v[i] - a.v[i]; }
+    n[0] = e1[1] * e2[2] - e1[2] * e2[1];
+    n[1] = e1[2] * e2[0] - e1[0] * e2[2];
+    n[2] = e1[0] * e2[1] - e1[1] * e2[0];
+    const double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    if (!(len > 1e-12 * scale * scale)) return;  // degenerate: not clipping keeps a superset
+    for (int i = 0; i < 3; ++i) n[i] /= len;
+    n[3] = -(n[0] * a.v[0] + n[1] * a.v[1] + n[2] * a.v[2]);
+    if (n[0] * cen[0] + n[1] * cen[1] + n[2] * cen[2] + n[3] < 0)
+      for (int i = 0; i < 4; ++i) n[i] = -n[i];
+    // every corner of the pyramid stays inside (fp slack, sides that are not exactly planar)
+    double worst = 0;
+    for (int c = 0; c < 4; ++c)
+      for (int e = 0; e < 2; ++e)
+        worst = std::min(worst, n[0] * F[c][e].v[0] + n[1] * F[c][e].v[1] + n[2] * F[c][e].v[2] + n[3]);
+    n[3] += -worst + 1e-6 * scale;
+    for (int i = 0; i < 4; ++i) planes[npl][i] = n[i];
+    ++npl;
+  };
+  for (int c = 0; c < 4; ++c) add_plane(F[c][0], F[c][1], F[(c + 1) & 3][0]);
+  add_plane(F[0][0], F[1][0], F[2][0]);
+  add_plane(F[0][1], F[1][1], F[2][1]);
+
+  const double eps = 1e-3;
+  double lo[3], hi[3];
+  for (int a = 0; a < 3; ++a) { lo[a] = (double)P.lo[a] - eps; hi[a] = (double)P.hi[a] + eps; }
+  double mn = 1e300, mx = -1e300;
+  for (int c = 0; c < 4; ++c)
+    for (int e = 0; e < 2; ++e) {
+      const double *p = F[c][e].v;
+      if (p[0] >= lo[0] && p[0] <= hi[0] && p[1] >= lo[1] && p[1] <= hi[1] && p[2] >= lo[2] && p[2] <= hi[2]) {
+        mn = std::min(mn, p[as]);
+        mx = std::max(mx, p[as]);
+      }
+    }
+  for (int a = 0; a < 3; ++a)
+    for (int side = 0; side < 2; ++side) {
+      const int b = (a + 1) % 3, c = (a + 2) % 3;
+      SlabVec poly[2][24];
+      const double bb[4] = {lo[b], hi[b], hi[b], lo[b]}, cc[4] = {lo[c], lo[c], hi[c], hi[c]};
+      for (int k = 0; k < 4; ++k) {
+        poly[0][k].v[a] = side ? hi[a] : lo[a];
+        poly[0][k].v[b] = bb[k];
+        poly[0][k].v[c] = cc[k];
+      }
+      int n = 4, cur = 0;
+      for (int k = 0; k < npl && n > 0; ++k) {
+        n = slab_clip_polygon(poly[cur], n, planes[k], poly[cur ^ 1]);
+        cur ^= 1;
+      }
+      for (int k = 0; k < n; ++k) {
+        mn = std::min(mn, poly[cur][k].v[as]);
+        mx = std::max(mx, poly[cur][k].v[as]);
+      }
+    }
+  if (!(mn <= mx)) return false;
+  *smin = std::max(mn, (double)P.lo[as]);
+  *smax = std::min(mx, (double)P.hi[as]);
+  return true;
+}
+}  // namespace
+
 template <int DT, int SH, int PERM, int NW, int NL, bool DIAG>
 static hipError_t launch_slab(const RenderParams &P, const SlabParams &Q, size_t lds, int nblocks, hipStream_t s) {
   auto k = smk_k_slab<DT, SH, PERM, NW, NL, DIAG>;
@@ -1028,44 +1139,31 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     for (int tyi = 0; tyi < P.nty; ++tyi)
       for (int txi = 0; txi < P.ntx; ++txi) {
         double cA[4][3], cB[4][3];
-        double smin_t = 1e300, smax_t = -1e300;
         for (int c = 0; c < 4; ++c) {
           int cx = std::min(txi * tw + ((c & 1) ? tw - 1 : 0), P.W - 1);
           int cy = std::min(tyi * th + ((c & 2) ? th - 1 : 0), P.H - 1);
           double *A = cA[c], *B = cB[c];
           host_ray(P, cx, cy, A, B);
-          {  // the ray's stretch inside the region, as slices along S
-            double t0 = 0, t1 = P.rc.nplanes - 1;
-            bool miss = false;
-            for (int a = 0; a < 3; ++a) {
-              if (fabs(B[a]) > 1e-20) {
-                double ta = (P.lo[a] - A[a]) / B[a], tb = (P.hi[a] - A[a]) / B[a];
-                t0 = std::max(t0, std::min(ta, tb));
-                t1 = std::min(t1, std::max(ta, tb));
-              } else if (!(A[a] >= P.lo[a] && A[a] <= P.hi[a]))
-                miss = true;
-            }
-            if (!miss && t0 <= t1) {
-              double sa = A[as] + t0 * B[as], sb = A[as] + t1 * B[as];
-              smin_t = std::min(smin_t, std::min(sa, sb));
-              smax_t = std::max(smax_t, std::max(sa, sb));
-            }
-          }
           if (!(B[as] * Q.dir > 0) || fabs(B[as]) < 1e-12) { *why = "rays do not share a marching direction"; return hipErrorNotSupported; }
           double du = fabs(B[Q.au] / B[as]), dv = fabs(B[Q.av] / B[as]);
           if (du > 1.5 || dv > 1.5) { *why = "view too oblique for the principal axis"; return hipErrorNotSupported; }
           max_drift_u = std::max(max_drift_u, du);
           max_drift_v = std::max(max_drift_v, dv);
         }
-        if (!(smin_t <= smax_t)) continue;  // no corner ray meets the region: (almost) nothing to stream
+        // the slices this tile can stream: S-extent of its ray bundle inside the region (exact for
+        // the continuous bundle, see slab_bundle_slice_range)
+        double smin_t, smax_t;
+        if (!slab_bundle_slice_range(P, (double)(txi * tw), (double)(tyi * th), (double)std::min(txi * tw + tw, P.W),
+                                     (double)std::min(tyi * th + th, P.H), as, &smin_t, &smax_t))
+          continue;  // the bundle misses the region: nothing to stream
         work[(size_t)tyi * P.ntx + txi] = 16 + (int)(smax_t - smin_t);
         // cross-section of the bundle where THIS tile streams: it is linear in s (perspective), so
-        // the two ends of the tile's own slice range bound it.  The range is padded: an interior
-        // ray may enter up to a tile's drift earlier than every corner ray (a cube edge or vertex
-        // facing the eye), and windows reach one slice beyond the slices they serve.  (Bounding by
-        // the volume's S faces instead costs 25-30 % window area at a voxel per pixel: rays are not
-        // inside the volume where they are widest apart.)
-        const double pad = 4.0 + 3.0 * fabs(Bc[as]) + 0.5 * std::max(tw, th) * std::max(max_drift_u, max_drift_v);
+        // the two ends of the tile's own slice range bound it.  A sample at s reads slices floor(s)
+        // and floor(s)+1, and the window of slice j covers s in [j-1, j+1] (stretched by half a
+        // slice at the volume faces): 2.5 slices beyond the range.  (Bounding by the volume's S
+        // faces instead costs 25-30 % window area at a voxel per pixel: rays are not inside the
+        // volume where they are widest apart.)
+        const double pad = 2.5 + 1e-2;
         const double se[2] = {std::max(-0.5, smin_t - pad), std::min((double)P.N[as] - 0.5, smax_t + pad)};
         for (int f = 0; f < 2; ++f) {
           double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;

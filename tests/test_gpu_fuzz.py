@@ -1,0 +1,92 @@
+"""Seeded random frames: ragged volume sizes, any rotation, off-centre and close-up eyes, wide
+frusta, odd viewports, both voxel types, every classification / shading mode the slice-ring kernel
+takes.  Per case: the slice-ring frame must equal the gather kernel's bit for bit (or the kernel
+must decline with a reason, never fail), its status word must stay 0, and the frame must match the
+CPU checker within the suite's tolerance.  SMK_FUZZ_CASES / SMK_FUZZ_SEED widen the run by hand."""
+import os
+
+import numpy as np
+import pytest
+
+import _scenes as S
+from _scenes import O, push_scene
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+NCASES = int(os.environ.get("SMK_FUZZ_CASES", "40"))
+SEED = int(os.environ.get("SMK_FUZZ_SEED", "20240"))
+
+
+def random_scene(rng):
+    u = rng.random()
+    hi = 150 if u < 0.08 else 72 if u < 0.3 else 40
+    dims = tuple(int(rng.integers(2, hi + 1)) for _ in range(3))
+    if rng.random() < 0.2:                      # a slab-shaped volume: one axis very thin
+        a = int(rng.integers(0, 3))
+        dims = tuple(int(rng.integers(2, 5)) if i == a else d for i, d in enumerate(dims))
+    f32 = bool(rng.integers(0, 2))
+    vgh8, vghf, nrm = S.ragged_vgh(dims, seed=int(rng.integers(1, 1000)))
+    sc = O.Scene(vghf if f32 else vgh8, grad=nrm)
+    kind = ["cfg2", "cfg3", "cfg4"][int(rng.integers(0, 3))]
+    sc.tf_mode = 1
+    if kind == "cfg2":
+        sc.tf_vg, sc.tf_h = S.tf_cfg2()
+    else:
+        sc.tf_vg = S.tf_cfg3()
+    if kind == "cfg4":
+        sc.tf_h = S.tf_h(float(rng.uniform(0.2, 0.8)))
+        sc.third_axis = 1
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis) + 1e-9
+    sc.xform = O.rotation(tuple(float(a) for a in axis), float(rng.uniform(-180, 180)))
+    wide = 420 if u < 0.08 else 150
+    sc.width = int(rng.integers(9, wide))
+    sc.height = int(rng.integers(9, wide))
+    sc.steps = int(rng.integers(6, 2 * wide // 3 + 60))
+    sc.shade_mode = int(rng.integers(0, 3))
+    sc.use_spec = int(rng.integers(0, 2))
+    r = rng.random()
+    if r < 0.25:                                # close-up: strong perspective, part of the volume off screen
+        sc.eye = (float(rng.uniform(-.3, .3)), float(rng.uniform(-.3, .3)), -float(rng.uniform(1.6, 2.5)))
+        w = float(rng.uniform(0.15, 0.45))
+        sc.frustum = (-w, w, -w, w)
+    elif r < 0.5:                               # panned
+        sc.trans = (float(rng.uniform(-.6, .6)), float(rng.uniform(-.6, .6)), float(rng.uniform(-1, 1)))
+    elif r < 0.6:                               # asymmetric frustum
+        sc.frustum = (-0.03, 0.11, -0.09, 0.05)
+    return sc, kind, f32, dims
+
+
+def test_random_frames(gpu_renderer_factory):
+    rng = np.random.default_rng(SEED)
+    R = gpu_renderer_factory()
+    took = declined = 0
+    reasons = {}
+    try:
+        for case in range(NCASES):
+            sc, kind, f32, dims = random_scene(rng)
+            tag = "case %d (seed %d): %s dims %s f32 %d %dx%d x%d shade %d" % (
+                case, SEED, kind, dims, f32, sc.width, sc.height, sc.steps, sc.shade_mode)
+            ref = sc.render()
+            push_scene(R, sc)
+            R.set_option("kernel", 1)
+            a = R.render()
+            assert np.abs(a - ref).max() <= TOL, tag + ": gather kernel vs CPU checker %g" % np.abs(a - ref).max()
+            R.set_option("kernel", 2)
+            try:
+                b = R.render()
+            except Exception as e:                 # forced slice-ring kernel on a frame it does not take
+                assert "not applicable" in str(e), tag + ": " + str(e)
+                assert R.stat("slab_status") == 0, tag
+                declined += 1
+                reasons[str(e)[:110]] = reasons.get(str(e)[:110], 0) + 1
+                continue
+            finally:
+                R.set_option("kernel", 0)
+            assert R.stat("slab_status") == 0, tag
+            assert np.array_equal(a, b), tag + ": slice-ring vs gather %g" % np.abs(a - b).max()
+            took += 1
+    finally:
+        R.close()
+    print("slice-ring kernel took %d frames, declined %d: %s" % (took, declined, reasons))
+    assert took >= NCASES // 2, "slice-ring kernel declined %d of %d frames" % (declined, NCASES)
