@@ -20,6 +20,8 @@ SEED = int(os.environ.get("SMK_FUZZ_SEED", "20240"))
 def random_scene(rng):
     u = rng.random()
     hi = 150 if u < 0.08 else 72 if u < 0.3 else 40
+    if os.environ.get("SMK_FUZZ_BIG") == "1" and u < 0.08:
+        hi = 330                               # by hand: windows big enough for the 16-wave workgroups
     dims = tuple(int(rng.integers(2, hi + 1)) for _ in range(3))
     if rng.random() < 0.2:                      # a slab-shaped volume: one axis very thin
         a = int(rng.integers(0, 3))
@@ -54,12 +56,40 @@ def random_scene(rng):
         sc.trans = (float(rng.uniform(-.6, .6)), float(rng.uniform(-.6, .6)), float(rng.uniform(-1, 1)))
     elif r < 0.6:                               # asymmetric frustum
         sc.frustum = (-0.03, 0.11, -0.09, 0.05)
+    if rng.random() < 0.15:
+        sc.steps, sc.sample_rate = 0, float(rng.uniform(0.3, 2.5))
+    sc.shard = None
+    if rng.random() < 0.2 and min(dims) >= 4:  # one rank's brick region of a sort-last job
+        world = int(rng.choice([2, 4, 8]))
+        sc.shard = (int(rng.integers(0, world)), world)
     return sc, kind, f32, dims
+
+
+def one_case(R, sc, tag):
+    """returns None when both kernels rendered the frame, else the slice-ring kernel's reason for declining"""
+    ref = sc.render()
+    push_scene(R, sc)
+    R.set_option("kernel", 1)
+    a = R.render()
+    assert np.abs(a - ref).max() <= TOL, tag + ": gather kernel vs CPU checker %g" % np.abs(a - ref).max()
+    R.set_option("kernel", 2)
+    try:
+        b = R.render()
+    except Exception as e:                 # forced slice-ring kernel on a frame it does not take
+        assert "not applicable" in str(e), tag + ": " + str(e)
+        assert R.stat("slab_status") == 0, tag
+        return str(e).split("not applicable:")[-1].strip()[:80]
+    finally:
+        R.set_option("kernel", 0)
+    assert R.stat("slab_status") == 0, tag
+    assert np.array_equal(a, b), tag + ": slice-ring vs gather %g" % np.abs(a - b).max()
+    return None
 
 
 def test_random_frames(gpu_renderer_factory):
     rng = np.random.default_rng(SEED)
-    R = gpu_renderer_factory()
+    from simian_spacemonkey_amd import sortlast
+    R0 = gpu_renderer_factory()
     took = declined = 0
     reasons = {}
     try:
@@ -67,26 +97,56 @@ def test_random_frames(gpu_renderer_factory):
             sc, kind, f32, dims = random_scene(rng)
             tag = "case %d (seed %d): %s dims %s f32 %d %dx%d x%d shade %d" % (
                 case, SEED, kind, dims, f32, sc.width, sc.height, sc.steps, sc.shade_mode)
-            ref = sc.render()
-            push_scene(R, sc)
-            R.set_option("kernel", 1)
-            a = R.render()
-            assert np.abs(a - ref).max() <= TOL, tag + ": gather kernel vs CPU checker %g" % np.abs(a - ref).max()
-            R.set_option("kernel", 2)
+            R = R0
+            if sc.shard:
+                R = gpu_renderer_factory()         # (a context is sharded before its first upload)
+                R.set_shard(*sc.shard)
+                sc.region = sortlast.shard_region(sc.dims, *sc.shard)
+                tag += " shard %d/%d" % sc.shard
             try:
-                b = R.render()
-            except Exception as e:                 # forced slice-ring kernel on a frame it does not take
-                assert "not applicable" in str(e), tag + ": " + str(e)
-                assert R.stat("slab_status") == 0, tag
-                declined += 1
-                reasons[str(e)[:110]] = reasons.get(str(e)[:110], 0) + 1
-                continue
+                why = one_case(R, sc, tag)
             finally:
-                R.set_option("kernel", 0)
-            assert R.stat("slab_status") == 0, tag
-            assert np.array_equal(a, b), tag + ": slice-ring vs gather %g" % np.abs(a - b).max()
-            took += 1
+                if R is not R0:
+                    R.close()
+            if why:
+                declined += 1
+                reasons[why] = reasons.get(why, 0) + 1
+            else:
+                took += 1
     finally:
-        R.close()
+        R0.close()
     print("slice-ring kernel took %d frames, declined %d: %s" % (took, declined, reasons))
     assert took >= NCASES // 2, "slice-ring kernel declined %d of %d frames" % (declined, NCASES)
+
+
+def test_interactive_session_in_auto_mode(gpu_renderer_factory):
+    """A camera wandering for 60 frames with the kernel choice left to the library: trial frames,
+    measured tile weights and schedule refreshes all happen along the way, and every frame must be
+    the frame the gather kernel renders for that pose (the two kernels are bit-identical)."""
+    rng = np.random.default_rng(SEED + 1)
+    vgh8, vghf, nrm = S.ragged_vgh((72, 64, 56), seed=9)
+    sc = O.Scene(vghf, grad=nrm)
+    sc.tf_mode, sc.tf_vg, sc.tf_h, sc.third_axis = 1, S.tf_cfg3(), S.tf_h(0.5), 1
+    sc.width, sc.height, sc.steps, sc.shade_mode = 200, 168, 120, 1
+    A, B = gpu_renderer_factory(), gpu_renderer_factory()
+    try:
+        axis = np.array([0.3, 1.0, 0.1])
+        angle = 0.0
+        kernels = []
+        for frame in range(60):
+            axis = axis + 0.15 * rng.normal(size=3)
+            axis /= np.linalg.norm(axis)
+            angle += float(rng.uniform(2, 9))          # walks through every principal axis
+            sc.xform = O.rotation(tuple(float(a) for a in axis), angle)
+            push_scene(A, sc, upload=frame == 0)
+            push_scene(B, sc, upload=frame == 0)
+            A.set_option("kernel", 0)
+            B.set_option("kernel", 1)
+            a, b = A.render(), B.render()
+            kernels.append(A.last_frame_info()[0])
+            assert A.stat("slab_status") == 0
+            assert np.array_equal(a, b), "frame %d (kernel %d): %g" % (frame, kernels[-1], np.abs(a - b).max())
+        assert 2 in kernels                              # the slice-ring kernel did take part
+    finally:
+        A.close()
+        B.close()
