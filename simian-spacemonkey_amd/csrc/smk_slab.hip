@@ -615,8 +615,9 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           raw_lds_st_b32(&ctl[4 + lid], landed);
           if (prof) t_wait += (long long)__builtin_amdgcn_s_memtime() - t_mark;
         } else {
-          if (++idle > (1 << 22) || raw_lds_b32(&ctl[3])) {  // bounded spin (see consumers)
-            raw_lds_st_b32(&ctl[3], 1);
+          const int flagged = raw_lds_b32(&ctl[3]);
+          if (++idle > (1 << 22) || flagged) {  // bounded spin (see consumers)
+            if (!flagged) raw_lds_st_b32(&ctl[3], 1);  // (a violated window bound stays the reported cause)
             break;
           }
           __builtin_amdgcn_s_sleep(1);
@@ -689,8 +690,9 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             }
             if (count) n_waits += 1.f;
             for (int spins = 0; have < need; ++spins) {
-              if (spins > (1 << 22) || lds_ld(&ctl[3])) {  // bounded: never hang the GPU on a protocol bug
-                lds_st(&ctl[3], 1);
+              const int flagged = lds_ld(&ctl[3]);
+              if (spins > (1 << 22) || flagged) {  // bounded: never hang the GPU on a protocol bug
+                if (!flagged) lds_st(&ctl[3], 1);
                 have = 0x3ffffff0;
                 m1 = m - 1;
                 pb = SLAB_DONE;
@@ -1177,10 +1179,12 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
           max_ev = std::max(max_ev, vmax - vmin);
         }
       }
-    // a window spans s in [j-1, j+1] (2 slices of drift; 2.5 at the faces); a coordinate range of
-    // extent e touches at most ceil(e) + 2 texels (pair included); eps for the fp32 chains
-    int Wu = (int)ceil(max_eu + 2.5 * max_drift_u + 2 * SLAB_EPS) + 2;
-    int Wv = (int)ceil(max_ev + 2.5 * max_drift_v + 2 * SLAB_EPS) + 2;
+    // a window spans s in [j-1, j+1] (2 slices of drift; 2.5 at a face; 3 where slice 1 of a
+    // three-slice volume touches both); a coordinate range of extent e touches at most ceil(e) + 2
+    // texels (pair included); eps for the fp32 chains
+    const double span = P.N[as] <= 3 ? 3.0 : 2.5;
+    int Wu = (int)ceil(max_eu + span * max_drift_u + 2 * SLAB_EPS) + 2;
+    int Wv = (int)ceil(max_ev + span * max_drift_v + 2 * SLAB_EPS) + 2;
     if (dtype == 0) Wu = ((Wu + 1) & ~1) + 2;  // even width, even alignment of the origin
     Wu = std::min(Wu, Q.Du);
     Wv = std::min(Wv, Q.Dv);

@@ -89,6 +89,26 @@ def test_u8_odd_extents_take_the_slice_ring_kernel(R, dims, pose):
     assert np.array_equal(a, b) and np.abs(b - ref).max() <= TOL
 
 
+@pytest.mark.parametrize("dims", [(4, 19, 3), (19, 3, 4), (3, 4, 19), (2, 2, 2), (2, 30, 30), (38, 56, 31)])
+@pytest.mark.parametrize("pose", ["z+", "y-", "x+", "diag"])
+def test_thin_and_tiny_volumes(R, dims, pose):
+    """Two-, three- and four-slice volumes along the marching axis (the window of slice 1 of a
+    three-slice volume reaches both faces) and volumes that project inside ONE pixel tile (all four
+    corner rays of the tile miss them): found by the random-frame test, pinned here."""
+    for f32 in (False, True):
+        sc = make_scene("cfg3", dims=dims, shade=1, pose=pose, f32=f32)
+        sc.width, sc.height = 31, 25
+        sc.steps, sc.sample_rate = 0, 1.64
+        ref = sc.render()
+        a, b = _both(R, sc)
+        assert np.array_equal(a, b) and np.abs(b - ref).max() <= TOL
+        sc.width, sc.height = 139, 107
+        sc.trans = (-0.15, 0.24, -0.21)
+        ref = sc.render()
+        a, b = _both(R, sc, upload=False)
+        assert np.array_equal(a, b) and np.abs(b - ref).max() <= TOL
+
+
 def test_sample_rate_mode_and_many_planes(R):
     sc = make_scene("cfg3", n=32, size=64, pose="y-", f32=True, shade=1)
     sc.steps, sc.sample_rate = 0, 3.3          # more planes than slices: several samples per slice

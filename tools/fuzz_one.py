@@ -26,19 +26,30 @@ def main():
         if case not in want:
             continue
         print("== case %d: %s dims %s f32 %d %dx%d x%d shade %d" % (case, kind, dims, f32, sc.width, sc.height, sc.steps, sc.shade_mode), flush=True)
-        push_scene(R, sc)
-        R.set_option("kernel", 1)
-        a = R.render()
-        R.set_option("kernel", 2)
-        for extra in ([], [("lockstep", 16)]):
-            for k, v in extra:
-                R.set_option(k, v)
+        r = R
+        if sc.shard:
+            from simian_spacemonkey_amd import sortlast
+            r = pkg.Renderer(0)
+            r.set_shard(*sc.shard)
+            sc.region = sortlast.shard_region(sc.dims, *sc.shard)
+        print("   rate %.3f eye %s trans %s frustum %s shard %s" % (sc.sample_rate, sc.eye, sc.trans, sc.frustum, sc.shard))
+        try:
+            print("   ->", F.one_case(r, sc, ""), flush=True)
+        except Exception as e:
+            print("   FAILED " + str(e)[-300:], flush=True)
+        ref = sc.render()
+        for k in (1, 2):
+            r.set_option("kernel", k)
             try:
-                b = R.render()
-                print("   ok, equal to gather: %s" % np.array_equal(a, b), flush=True)
+                img = r.render()
+                d = np.abs(img - ref)
+                j, i = np.unravel_index(d.max(axis=2).argmax(), d.shape[:2])
+                print("   kernel %d vs CPU: max %g at pixel (%d,%d): gpu %s cpu %s" % (k, d.max(), i, j, img[j, i], ref[j, i]), flush=True)
             except Exception as e:
-                print("   " + str(e)[:100], flush=True)
-            R.set_option("lockstep", 0)
+                print("   kernel %d: %s" % (k, str(e)[-200:]))
+        r.set_option("kernel", 0)
+        if r is not R:
+            r.close()
     R.close()
 
 
