@@ -150,3 +150,55 @@ def test_interactive_session_in_auto_mode(gpu_renderer_factory):
     finally:
         A.close()
         B.close()
+
+
+def test_random_frames_gather_only_modes(gpu_renderer_factory):
+    """The modes only the gather kernel takes -- 1-D TLUT on scalar data, dense 3-D transfer
+    function, noise-perturbed fetches, first-hit depth, bricked uploads -- on random volumes and
+    poses, against the CPU checker."""
+    rng = np.random.default_rng(SEED + 2)
+    R = gpu_renderer_factory()
+    try:
+        for case in range(max(12, NCASES // 2)):
+            dims = tuple(int(rng.integers(5, 41)) for _ in range(3))
+            mode = ["cfg1", "tf3d", "pert", "depth", "bricks"][case % 5]
+            if mode == "bricks":        # MetaVolume::brick drops the remainder voxels of an odd size
+                dims = tuple(max(8, d & ~1) for d in dims)   # (MetaVolume.cpp:1394-1396): keep it whole
+            f32 = bool(rng.integers(0, 2))
+            if mode == "cfg1":
+                nz, ny, nx = dims[2], dims[1], dims[0]
+                v = rng.integers(0, 256, size=(nz, ny, nx, 1), dtype=np.uint8)
+                sc = O.Scene(v)
+                sc.tf_mode, sc.tlut = 0, O.tlut_volumerenderable()
+            else:
+                vgh8, vghf, nrm = S.ragged_vgh(dims, seed=int(rng.integers(1, 1000)))
+                sc = O.Scene(vghf if f32 else vgh8, grad=nrm)
+                sc.tf_mode, sc.tf_vg = 1, S.tf_cfg3()
+                if mode == "tf3d":
+                    sc.tf_mode, sc.tf3d = 2, S.tf3d_dense()
+                if mode == "pert":
+                    sc.noise = O.noise_tex(32)
+                    sc.pert_w = (float(rng.uniform(0, .3)), float(rng.uniform(0, .2)), 0, 0)
+                    sc.pert_s = (.2, 2.1, 4.5, 8.7)
+            axis = rng.normal(size=3)
+            axis /= np.linalg.norm(axis) + 1e-9
+            sc.xform = O.rotation(tuple(float(a) for a in axis), float(rng.uniform(-180, 180)))
+            sc.width, sc.height = int(rng.integers(9, 120)), int(rng.integers(9, 120))
+            sc.steps = int(rng.integers(6, 120))
+            sc.shade_mode = 0 if mode == "cfg1" else int(rng.integers(0, 3))
+            tag = "case %d (seed %d): %s dims %s f32 %d %dx%d x%d shade %d" % (
+                case, SEED + 2, mode, dims, f32, sc.width, sc.height, sc.steps, sc.shade_mode)
+            grid = (2, 2, 2) if mode == "bricks" else (1, 1, 1)
+            push_scene(R, sc, grid)
+            R.set_option("kernel", 0)
+            if mode == "depth":
+                ref, rd = sc.render(depth=True)
+                img, dep = R.render(depth=True)
+                fin = np.isfinite(rd)
+                assert np.array_equal(fin, np.isfinite(dep)), tag
+                assert not fin.any() or np.abs(rd[fin] - dep[fin]).max() <= 1e-4, tag
+            else:
+                ref, img = sc.render(), R.render()
+            assert np.abs(img - ref).max() <= TOL, tag + ": %g" % np.abs(img - ref).max()
+    finally:
+        R.close()
