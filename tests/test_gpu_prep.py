@@ -89,3 +89,37 @@ def test_device_upload_matches_host_upload(R, O):
     push_scene(R, sc, upload=False)
     b = R.render()
     assert np.array_equal(a, b)
+
+
+def test_random_sizes_bit_exact(R, O):
+    """ragged sizes down to the smallest the entry points take (3 voxels per axis: the derivative
+    stencils need an interior): VGH synthesis and normals (with and without the 27-tap blur) stay
+    bit-exact; smaller volumes are refused, not mis-computed"""
+    import torch
+    rng = np.random.default_rng(99)
+    with pytest.raises(Exception, match="dims >= 3"):
+        R.make_vgh_device(_dev(np.zeros((2, 5, 5), np.uint8)).data_ptr(), 0, (5, 5, 2), 1,
+                          torch.zeros((2, 5, 5, 3), dtype=torch.uint8, device="cuda").data_ptr(), None)
+    sizes = [(3, 3, 3), (3, 17, 4), (41, 3, 7), (5, 4, 3)]
+    sizes += [tuple(int(rng.integers(3, 45)) for _ in range(3)) for _ in range(10)]
+    for dims in sizes:
+        nx, ny, nz = dims
+        v = rng.integers(0, 256, size=(nz, ny, nx), dtype=np.uint8)
+        if nx > 4 and ny > 4 and nz > 4:
+            v[1:4, 1:4, 1:4] = 200     # flat patch: zero gradient
+        for compat in (1, 0):
+            ref8, reff = O.make_vgh(v, compat=bool(compat), f32=True)
+            o8 = torch.zeros((nz, ny, nx, 3), dtype=torch.uint8, device="cuda")
+            of = torch.zeros((nz, ny, nx, 3), dtype=torch.float32, device="cuda")
+            R.make_vgh_device(_dev(v).data_ptr(), 0, dims, compat, o8.data_ptr(), of.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(o8.cpu().numpy(), ref8), (dims, compat)
+            # (one interior voxel: the normalisation range is 0 and both sides emit the same NaNs)
+            assert np.array_equal(of.cpu().numpy(), reff, equal_nan=True), (dims, compat)
+        vgh = O.make_vgh(v)
+        for blur in (0, 1):
+            ref = O.normals_vgh(vgh, blur=bool(blur))
+            out = torch.zeros((nz, ny, nx, 3), dtype=torch.uint8, device="cuda")
+            R.normals_vgh_device(_dev(vgh).data_ptr(), 3, dims, blur, out.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), ref), (dims, blur)
