@@ -721,7 +721,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
         if (work) {
           // the two slices' slot images (one 8-byte table entry each, adjacent): issued first,
           // the position arithmetic below covers the LDS round trip
-          const int *te = reinterpret_cast<const int *>(smem + (wtab_addr - ring_addr)) + 2 * (psgn * pb + eoff);
+          const int *te = reinterpret_cast<const int *>(smem + (wtab_addr - ring_addr)) + 2 * (__mul24(psgn, pb) + eoff);  // (24-bit multiply: full rate; |pb| < 4096 on a lane that works)
           const int base_a = te[0], base_b = te[2];
           const float mf = (float)m;
           const float p0 = __fmaf_rn(mf, B[0], A[0]), p1 = __fmaf_rn(mf, B[1], A[1]), p2 = __fmaf_rn(mf, B[2], A[2]);
@@ -741,7 +741,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           // a classification + shading later -- on a 5-slot ring the loaders otherwise sit blocked
           // for most of the consumers' iteration
           int pbn = pb;
-          if (act) pbn = (m + 1 <= m1) ? psgn * base_slice(m + 1) + poff : SLAB_DONE;
+          if (act) pbn = (m + 1 <= m1) ? __mul24(psgn, base_slice(m + 1)) + poff : SLAB_DONE;
           const int plo = wave_min_i32(pbn);
           if (plo != pos && plo < SLAB_DONE) {
             pos = plo;
@@ -887,7 +887,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
         }
         if (act) {
           ++m;
-          pb = (m <= m1) ? psgn * base_slice(m) + poff : SLAB_DONE;
+          pb = (m <= m1) ? __mul24(psgn, base_slice(m)) + poff : SLAB_DONE;
         }
         if (count) {
           n_it += 1.f;
