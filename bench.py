@@ -349,7 +349,10 @@ def main():
                          "frac": ach2 / HBM_PEAK_GBPS,
                          "traffic": pmc_traffic("north_star") if default_workload and nn_ == 1024 else None,
                          "kernel_ms": kms2,
-                         "algorithmic_bytes_per_launch": alg2},
+                         "algorithmic_bytes_per_launch": alg2,
+                         # SURVEY 8(d) counts the f32 VGH triple alone (12 B/voxel); alg2 adds the 3
+                         # normal bytes per voxel the Phong term reads
+                         "frac_on_vgh_bytes_only": (alg2 - 3.0 * nn_ ** 3) / (kms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS if kms2 > 0 else 0.0},
             "kernel": {1: "gather", 2: "slab-staged"}.get(kernel2, str(kernel2))}
     if rank == 0:
         print(json.dumps(out))
