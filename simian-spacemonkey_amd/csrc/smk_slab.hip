@@ -1124,6 +1124,8 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
   else if (opt_tile == 9) { cfgs[0] = {16, 32, 1}; ncfg = 1; }
   else if (opt_tile == 10) { cfgs[0] = {24, 32, 2}; ncfg = 1; }
   else if (opt_tile == 11) { cfgs[0] = {24, 24, 2}; ncfg = 1; }
+  else if (opt_tile == 12) { cfgs[0] = {48, 16, 4}; ncfg = 1; }
+  else if (opt_tile == 13) { cfgs[0] = {16, 48, 4}; ncfg = 1; }
   const int upv = dtype == 0 ? 2 : 1;
   for (int ci = 0; ci < ncfg; ++ci) {
     const int tw = cfgs[ci].tw, th = cfgs[ci].th, nl = cfgs[ci].nl;
