@@ -1,11 +1,14 @@
 // Drives the host-side mirror the way Simian's main() drives a renderer (gluvv.cpp:141-199,
 // 518-525, 593-597): fill `gluvv`, new the primitive, link it, init() once, draw() per frame.
 // usage: adapter_main <vol.u8 nx ny nz nelts> <grad.u8|-> <deptex.rgba|-> <W> <H> <rate> <shade 0|3> <xform16...> <out.f32>
+//        adapter_main <dataset.trex 0 0 0 1> ...   the volume comes from disk the way `gluvv data.trex` loads it
+//                                                   (MetaVolume(file) + readAll(tstart), gluvv.cpp:160-176)
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 
 #include "HipVolumeRenderer.h"
+#include "VolumeFiles.h"
 
 gluvvGlobal gluvv;
 
@@ -28,7 +31,19 @@ int main(int argc, char **argv) {
     return 2;
   }
   int a = 1;
-  auto vol = slurp(argv[a++]);
+  const std::string first = argv[1];
+  const bool from_trex = first.size() > 5 && first.substr(first.size() - 5) == ".trex";
+  smkfiles::LoadedVolume loaded;
+  if (from_trex) {
+    std::string err;
+    smkfiles::TrexHeader peek;
+    if (smkfiles::parse_trex(argv[1], &peek, &err) != 1 || !smkfiles::load_trex(argv[1], peek.tstart, &loaded, &err)) {
+      fprintf(stderr, "%s\n", err.c_str());
+      return 5;
+    }
+  }
+  auto vol = from_trex ? std::vector<unsigned char>() : slurp(argv[a]);
+  ++a;
   int nx = atoi(argv[a++]), ny = atoi(argv[a++]), nz = atoi(argv[a++]), ne = atoi(argv[a++]);
   auto grad = slurp(argv[a++]);
   auto dep = slurp(argv[a++]);
@@ -38,7 +53,7 @@ int main(int argc, char **argv) {
   gluvv.shade = (gluvvShade)atoi(argv[a++]);
   for (int i = 0; i < 16; ++i) gluvv.rinfo.xform[i] = (float)atof(argv[a++]);
   const char *out = argv[a++];
-  if (vol.size() != (size_t)nx * ny * nz * ne) {
+  if (!from_trex && vol.size() != (size_t)nx * ny * nz * ne) {
     fprintf(stderr, "volume size mismatch\n");
     return 2;
   }
@@ -53,7 +68,7 @@ int main(int argc, char **argv) {
   mv.volumes = &v;
   mv.numSubVols = 1;
   mv.nelts = ne;
-  gluvv.mv = &mv;
+  gluvv.mv = from_trex ? &loaded.mv : &mv;
   gluvv.dmode = ne == 1 ? GDM_V1 : GDM_VGH;
   const float fr = 0.5f / 7;
   gluvv.env.frustum[0] = -fr; gluvv.env.frustum[1] = fr; gluvv.env.frustum[2] = -fr; gluvv.env.frustum[3] = fr;

@@ -68,3 +68,47 @@ def test_vgh_path_like_nv20volren3d(tmp_path, O):
     got = np.fromfile(out, np.float32).reshape(sc.height, sc.width, 4)
     ref = sc.render()
     assert ref[..., 3].max() > 0.05 and np.abs(got - ref).max() <= 1e-4
+
+
+@pytest.mark.gpu
+def test_dataset_loaded_from_trex_files_renders_like_the_checker(tmp_path, O):
+    """The whole load path of `gluvv data.trex`: a big-endian float data set in two pre-bricked raw
+    files + its .trex description -> VolumeFiles (parse, read, byte-swap, min/max quantise) ->
+    the adapter's init()/draw().  The CPU checker renders the same quantised voxels."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import volume_files as VF
+    rng = np.random.default_rng(4)
+    nx, ny, nz = 24, 20, 16
+    z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    native = (np.sin(x * .4) * np.cos(y * .3) * 40 + z * 3 + rng.normal(0, 2, x.shape)).astype(np.float32)
+    q = VF.quantize(native)                      # one min/max per FILE in the reference: brick by brick
+    base = tmp_path / "met"
+    halves = [native[:, :, :nx // 2], native[:, :, nx // 2:]]
+    for b, h in enumerate(halves):
+        np.ascontiguousarray(h).astype(">f4").tofile("%s.0000.%02d" % (base, b))
+    trex = tmp_path / "met.trex"
+    trex.write_text("Data Set Name: met\nData Set Files: %s\nNumber of Time Steps: 1, 0, 0\nData Type: float\nEndian: big\n"
+                    "Volume Size int: %d, %d, %d\nVolume Size float: 1, %.9g, %.9g\nNumber of Sub Volumes: 2\n"
+                    "SubVolume {\n Size int: %d, %d, %d\n Size float: .5, %.9g, %.9g\n Pos int: 0, 0, 0\n Pos float: 0, 0, 0\n}\n"
+                    "SubVolume {\n Size int: %d, %d, %d\n Size float: .5, %.9g, %.9g\n Pos int: %d, 0, 0\n Pos float: .5, 0, 0\n}\n"
+                    % (base, nx, ny, nz, ny / nx, nz / nx, nx // 2, ny, nz, ny / nx, nz / nx,
+                       nx // 2, ny, nz, ny / nx, nz / nx, nx // 2))
+    whole = np.concatenate([VF.quantize(h) for h in halves], axis=2)
+    assert whole.shape == q.shape
+    sc = O.Scene(np.ascontiguousarray(whole)[..., None])
+    sc.tf_mode = 0
+    sc.xform = O.rotation((1, 1, 0), 30)
+    sc.width = sc.height = 40
+    sc.steps, sc.sample_rate = 0, 1.5
+    t = O.tlut("default", 256)
+    t[:, 3] = (0.1 * np.arange(256) / 255).astype(np.float32)
+    sc.tlut = O.tlut_scale_alpha(t, 1.0, 1.5)
+    out = tmp_path / "frame.f32"
+    cmd = [EXE, str(trex), "0", "0", "0", "1", "-", "-", str(sc.width), str(sc.height), repr(1.5), "1"] + \
+          [repr(float(v)) for v in sc.xform] + [str(out)]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    got = np.fromfile(out, np.float32).reshape(sc.height, sc.width, 4)
+    ref = sc.render()
+    assert ref[..., 3].max() > 0.05 and np.abs(got - ref).max() <= 1e-4
