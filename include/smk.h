@@ -107,6 +107,11 @@ int smk_set_sampling(smk_ctx *ctx, float sample_rate, int steps, float gamma, in
 /* replaces R8kVolRen3D_cpy::createNoiseTex + gluvv.pert (R8kVolRen3D_cpy.cpp:2392-2480,
  * 1590-1595): n^3 RGBA8 noise (GL_REPEAT), weights/scales of the two live octaves. noise NULL
  * or all weights 0 turns perturbation off. */
+/* replaces the orthogonal mode of the clip-plane widget (gluvv.clip.{on,ortho,oaxis,vpos},
+ * gluvv.h:163-175; NV20VolRen3D::setupClips, NV20VolRen3D.cpp:251-327): the volume is drawn only
+ * on one side of an axis-aligned plane through vpos (volume space, the units of fPos/fSize).
+ * oaxis = VolRenMajorAxis: 1 X+ (x <= vpos.x stays), 2 X-, 3 Y+, 4 Y-, 5 Z+, 6 Z-.  on = 0: off. */
+int smk_set_clip(smk_ctx *ctx, int on, int oaxis, const float vpos[3]);
 int smk_set_perturb(smk_ctx *ctx, const unsigned char *noise_rgba, int n, const float w[4],
                     const float s[4]);
 

@@ -35,7 +35,8 @@ class Volume(C.Structure):
     _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("nelts", C.c_int),
                 ("dtype", C.c_int), ("data", C.c_void_p), ("grad", C.c_void_p),
                 ("fx", C.c_float), ("fy", C.c_float), ("fz", C.c_float),
-                ("g0", C.c_int * 3), ("g1", C.c_int * 3)]
+                ("g0", C.c_int * 3), ("g1", C.c_int * 3),
+                ("clip_axis", C.c_int), ("clip_vpos", C.c_float * 3)]
 
 
 class Classify(C.Structure):
@@ -190,6 +191,7 @@ class Scene:
         self.noise = None
         self.pert_w, self.pert_s = (0, 0, 0, 0), (0.2, 2.1, 4.5, 8.7)   # gluvvui.cpp:213-267
         self.mv_override = None
+        self.clip = None        # (axis 1..6 = X+ X- Y+ Y- Z+ Z-, vpos[3] in volume space): gluvv.clip, ortho mode
 
     def mv(self):
         if self.mv_override is not None:
@@ -207,6 +209,8 @@ class Scene:
         v.fx, v.fy, v.fz = self.fsize
         v.g0[:] = self.region[0]
         v.g1[:] = self.region[1]
+        v.clip_axis = self.clip[0] if self.clip else 0
+        v.clip_vpos[:] = self.clip[1] if self.clip else (0, 0, 0)
         return v
 
     def c_classify(self):

@@ -419,6 +419,22 @@ static long long march_pixel(const orc_volume *v, const orc_classify *tf, const 
     hi[a] = (float)v->g1[a] - 0.5f;
     top[a] = v->g1[a] == N[a]; /* outer face inclusive, interior faces half-open */
   }
+  /* Orthogonal clip plane (NV20VolRen3D::setupClips, NV20VolRen3D.cpp:251-327): the box a brick is
+   * sliced in ends at the plane -- the corners on the far side of it move to cp = vpos clamped into
+   * the box -- so samples beyond it do not exist.  In voxel coordinates the face sits at
+   * cp/fSize * N - 1/2 (texture coordinate cp/fSize, edge-to-edge mapping); it is an outer face of
+   * what is drawn, hence inclusive. */
+  if (v->clip_axis >= 1 && v->clip_axis <= 6) {
+    const int a = (v->clip_axis - 1) / 2;
+    const float fs = a == 0 ? v->fx : (a == 1 ? v->fy : v->fz);
+    float cp = v->clip_vpos[a] > 0.0f ? (v->clip_vpos[a] < fs ? v->clip_vpos[a] : fs) : 0.0f;
+    const float face = (float)((double)cp / (double)fs * (double)N[a] - 0.5);
+    if ((v->clip_axis - 1) % 2 == 0) {  /* X+ : what lies below the plane stays */
+      if (face < hi[a] || (face == hi[a] && !top[a])) { hi[a] = face; top[a] = 1; }
+    } else if (face > lo[a]) {
+      lo[a] = face;
+    }
+  }
   float C[4] = {0, 0, 0, 0};
   float first = INFINITY;
   long long inside = 0;

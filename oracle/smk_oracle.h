@@ -34,6 +34,8 @@ typedef struct {
   const unsigned char *grad; /* [nz][ny][nx][3] scale-biased normals or NULL               */
   float fx, fy, fz;          /* extent in model space (Volume::x/y/zfSize)                 */
   int g0[3], g1[3];          /* region [g0,g1) in voxel indices (x,y,z)                    */
+  int clip_axis;             /* orthogonal clip plane: 0 off, 1..6 = X+ X- Y+ Y- Z+ Z- (VolRenMajorAxis, gluvv.h:136-144) */
+  float clip_vpos[3];        /* its position in volume space (gluvv.clip.vpos)             */
 } orc_volume;
 
 enum { ORC_TF_1D = 0, ORC_TF_2D = 1, ORC_TF_3D = 2 };

@@ -16,7 +16,7 @@ _LIB = None
 
 ABI_SYMBOLS = [
     "smk_create", "smk_destroy", "smk_last_error", "smk_upload_volume",
-    "smk_upload_volume_device", "smk_set_shard", "smk_shard_order", "smk_set_tlut1d",
+    "smk_upload_volume_device", "smk_set_shard", "smk_set_clip", "smk_shard_order", "smk_set_tlut1d",
     "smk_set_tf2d", "smk_set_tf3d", "smk_set_camera", "smk_set_shading", "smk_set_sampling",
     "smk_set_perturb", "smk_render", "smk_render_device", "smk_composite_over_device",
     "smk_make_vgh_device", "smk_normals_vgh_device", "smk_synth_volume_device",
@@ -86,6 +86,7 @@ def load_library():
     for n in ("smk_upload_volume", "smk_upload_volume_device"):
         getattr(L, n).argtypes = [C.c_void_p, P(VolumeDesc), C.c_int, C.c_int, C.c_int, C.c_int]
     L.smk_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.smk_set_clip.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.smk_shard_order.argtypes = [C.c_void_p, P(C.c_int)]
     L.smk_set_tlut1d.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.smk_set_tf2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -246,6 +247,14 @@ class Renderer:
 
     def set_sampling(self, sample_rate=0.0, steps=0, gamma=1.0, scale_alphas=1):
         self._ck(self.L.smk_set_sampling(self.ctx, sample_rate, steps, gamma, scale_alphas))
+
+    def set_clip(self, axis, vpos):
+        """orthogonal clip plane: axis 1..6 = X+ X- Y+ Y- Z+ Z- (VolRenMajorAxis), vpos in volume space;
+        axis 0 / None switches it off"""
+        if not axis:
+            self._ck(self.L.smk_set_clip(self.ctx, 0, 0, None))
+        else:
+            self._ck(self.L.smk_set_clip(self.ctx, 1, int(axis), _fa(vpos)))
 
     def set_perturb(self, noise, w, s):
         if noise is None:

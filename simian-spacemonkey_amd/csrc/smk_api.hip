@@ -285,6 +285,18 @@ extern "C" int smk_upload_volume_device(smk_ctx *c, const smk_volume_desc *b, in
   return upload_impl(c, b, nb, nelts, dt, dm, true);
 }
 
+extern "C" int smk_set_clip(smk_ctx *c, int on, int oaxis, const float *vpos) {
+  if (!c) return 1;
+  if (!on) {
+    c->clip_axis = 0;
+    return 0;
+  }
+  if (oaxis < 1 || oaxis > 6 || !vpos) FAIL(c, "smk_set_clip: axis must be 1..6 (X+ X- Y+ Y- Z+ Z-) and vpos given");
+  c->clip_axis = oaxis;
+  for (int a = 0; a < 3; ++a) c->clip_vpos[a] = vpos[a];
+  return 0;
+}
+
 extern "C" int smk_set_shard(smk_ctx *c, int rank, int nranks) {
   if (!c) return 1;
   if (!(nranks == 1 || nranks == 2 || nranks == 4 || nranks == 8)) FAIL(c, "smk_set_shard: nranks must be 1,2,4 or 8");
@@ -754,9 +766,22 @@ static int build_params(smk_ctx *c, RenderParams &P) {
     P.lo[a] = (float)c->g0[a] - 0.5f;
     P.hi[a] = (float)c->g1[a] - 0.5f;
     P.top[a] = c->g1[a] == c->N[a];
-    P.hin[a] = P.top[a] ? P.hi[a] : nextafterf(P.hi[a], -INFINITY);
     P.invN[a] = 1.0f / (float)c->N[a];
   }
+  // orthogonal clip plane (NV20VolRen3D::setupClips, NV20VolRen3D.cpp:251-327): the sliced box ends
+  // at the plane, i.e. the region shrinks along one axis; the new face is an outer (inclusive) one
+  if (c->clip_axis >= 1 && c->clip_axis <= 6) {
+    const int a = (c->clip_axis - 1) / 2;
+    const float fs = c->fsize[a];
+    const float cp = c->clip_vpos[a] > 0.0f ? (c->clip_vpos[a] < fs ? c->clip_vpos[a] : fs) : 0.0f;
+    const float face = (float)((double)cp / (double)fs * (double)c->N[a] - 0.5);
+    if ((c->clip_axis - 1) % 2 == 0) {
+      if (face < P.hi[a] || (face == P.hi[a] && !P.top[a])) { P.hi[a] = face; P.top[a] = 1; }
+    } else if (face > P.lo[a]) {
+      P.lo[a] = face;
+    }
+  }
+  for (int a = 0; a < 3; ++a) P.hin[a] = P.top[a] ? P.hi[a] : nextafterf(P.hi[a], -INFINITY);
   P.nelts = c->nelts;
   P.n_in_w = (c->dtype == SMK_F32 && c->nelts <= 3) ? 1 : 0;
   P.tlut = c->d_tlut;

@@ -100,6 +100,8 @@ struct smk_ctx {
   int g0[3] = {0, 0, 0}, g1[3] = {0, 0, 0};  // this context's region
   int O[3] = {0, 0, 0}, D[3] = {0, 0, 0};
   int halo = 1;
+  int clip_axis = 0;  // orthogonal clip plane: 0 off, 1..6 = X+ X- Y+ Y- Z+ Z-
+  float clip_vpos[3] = {0, 0, 0};
   void *d_vox = nullptr;
   void *d_vox_x = nullptr;  // x-major copy [x][z][y] for views whose principal axis is x (lazy)
   std::string slab_why;     // why the last frame fell back to the gather kernel ("" if it did not)

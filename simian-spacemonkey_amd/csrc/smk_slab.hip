@@ -1100,6 +1100,10 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
   if (Q.perm == 0) { Q.strideV = P.D[0]; Q.strideS = (long long)P.D[0] * P.D[1]; Q.vox = vox_native; }
   else if (Q.perm == 1) { Q.strideV = (long long)P.D[0] * P.D[1]; Q.strideS = P.D[0]; Q.vox = vox_native; }
   else { Q.strideV = P.D[1]; Q.strideS = (long long)P.D[1] * P.D[2]; Q.vox = vox_xmajor; }  // [x][z][y]
+  // an empty region (a clip plane outside a shard's box): the gather kernel's explicit comparisons
+  // render it as nothing; the median-of-three membership test here needs lo <= hi
+  for (int a = 0; a < 3; ++a)
+    if (!(P.lo[a] <= P.hin[a])) { *why = "region is empty"; return hipErrorNotSupported; }
   if (Q.Ds > 4096) { *why = "more than 4096 slices"; return hipErrorNotSupported; }
   // u8 voxels are 8 B: the DMA moves 16-B units, so rows must start and end on even voxels
   if (dtype == 0 && ((Q.Du & 1) || (Q.strideV & 1) || (Q.strideS & 1))) { *why = "odd U extent for 8-byte voxels"; return hipErrorNotSupported; }

@@ -126,6 +126,8 @@ void HipVolumeRenderable::draw() {
       std::cerr << "ERROR: HipVolumeRenderable::draw: " << smk_last_error(c) << std::endl;
     gluvv.volren.loadTLUT = 0;
   }
+  // clip-plane widget, orthogonal mode (NV20VolRen3D::setupClips, NV20VolRen3D.cpp:251-327)
+  smk_set_clip(c, gluvv.clip.on && gluvv.clip.ortho, (int)gluvv.clip.oaxis, gluvv.clip.vpos);
   smk_shade sm = SMK_SHADE_NONE;
   if (gluvv.shade == gluvvShadeDiff) sm = SMK_SHADE_R8K_DIFF;
   if (gluvv.shade == gluvvShadeDSpec) sm = SMK_SHADE_R8K_DSPEC;

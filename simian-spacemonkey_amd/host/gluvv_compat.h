@@ -61,6 +61,7 @@ class TLUT {
   float lastSampleRate;
 };
 
+typedef enum { VolRenAxisUnknown, VolRenAxisXPos, VolRenAxisXNeg, VolRenAxisYPos, VolRenAxisYNeg, VolRenAxisZPos, VolRenAxisZNeg } VolRenMajorAxis;  // gluvv.h:136-144
 typedef enum { gluvvShadeUnknown, gluvvShadeAmb, gluvvShadeDiff, gluvvShadeDSpec, gluvvShadeFaux, gluvvShadeArb, gluvvShadeMIP } gluvvShade;
 typedef enum {
   GDM_V1, GDM_V1G, GDM_V1GH, GDM_V2, GDM_V2G, GDM_V2GH, GDM_V3, GDM_V3G, GDM_V4, GDM_VGH, GDM_VGH_VG, GDM_VGH_V, GDM_UNKNOWN
@@ -84,6 +85,7 @@ struct gluvvGlobal {
     float gamma = 1;
   } volren;
   struct { int ptexsz[3] = {256, 256, 1}; int numelts = 4; } tf;
+  struct { int on = 0, ortho = 1; VolRenMajorAxis oaxis = VolRenAxisXPos; float vpos[3] = {0, 0, 0}; } clip;  // gluvvClip (gluvv.h:163-175), the fields the renderer reads
   struct { int on = 0; float weights[10] = {.2f, 0, 0, 0}, scales[10] = {.2f, 2.1f, 4.5f, 8.7f}; } pert;
   int picking = 0;
   int reblend = 0;

@@ -58,6 +58,9 @@ def random_scene(rng):
         sc.frustum = (-0.03, 0.11, -0.09, 0.05)
     if rng.random() < 0.15:
         sc.steps, sc.sample_rate = 0, float(rng.uniform(0.3, 2.5))
+    sc.clip = None
+    if rng.random() < 0.12:                    # the clip-plane widget in its orthogonal mode
+        sc.clip = (int(rng.integers(1, 7)), tuple(float(rng.uniform(0.1, 0.9)) * float(f) for f in sc.fsize))
     sc.shard = None
     if rng.random() < 0.2 and min(dims) >= 4:  # one rank's brick region of a sort-last job
         world = int(rng.choice([2, 4, 8]))

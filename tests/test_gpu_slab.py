@@ -209,3 +209,44 @@ def test_auto_mode_measures_both_kernels_and_settles(R):
     for f in frames[1:]:
         assert np.array_equal(f, frames[0])
     assert np.abs(frames[0] - sc.render()).max() <= TOL
+
+
+@pytest.mark.parametrize("axis", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("pose", ["rot", "x+"])
+def test_orthogonal_clip_plane(R, axis, pose):
+    """gluvv.clip in its orthogonal mode: the volume ends at an axis-aligned plane through vpos
+    (NV20VolRen3D.cpp:251-327) -- a smaller region for both kernels."""
+    sc = make_scene("cfg4", n=32, size=64, steps=72, pose=pose, f32=True, shade=1)
+    whole = sc.render()
+    sc.clip = (axis, (0.37, 0.52, 0.61))
+    ref = sc.render()
+    assert np.abs(ref - whole).max() > 0.02           # the plane does cut something away
+    a, b = _both(R, sc)
+    assert np.array_equal(a, b) and np.abs(b - ref).max() <= TOL
+    sc.clip = (axis, (-1.0, -1.0, -1.0) if axis % 2 else (2.0, 2.0, 2.0))   # everything clipped away
+    a, b = _both(R, sc, upload=False)
+    assert not a.any() and not b.any() and not sc.render().any()
+    sc.clip = None
+    a, b = _both(R, sc, upload=False)
+    assert np.array_equal(a, b) and np.abs(b - whole).max() <= TOL
+
+
+def test_clip_plane_outside_a_shard_leaves_it_empty(gpu_renderer_factory):
+    """a clip plane on the far side of a rank's brick region: nothing of that rank is visible; the
+    slice-ring kernel hands such frames to the gather kernel (its membership test needs lo <= hi)"""
+    from simian_spacemonkey_amd import sortlast
+    sc = make_scene("cfg2", dims=(70, 44, 56), shade=1, pose="rot")
+    sc.clip = (5, (0.44, 0.18, 0.11))                 # keeps z below ~7.5 voxels
+    r = gpu_renderer_factory()
+    try:
+        r.set_shard(4, 8)                              # owns z >= 28
+        push_scene(r, sc)
+        sc.region = sortlast.shard_region(sc.dims, 4, 8)
+        assert not sc.render().any()
+        r.set_option("kernel", 0)
+        assert not r.render().any() and r.last_frame_info()[0] == 1
+        r.set_option("kernel", 2)
+        with pytest.raises(Exception, match="region is empty"):
+            r.render()
+    finally:
+        r.close()

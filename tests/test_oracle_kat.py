@@ -236,3 +236,29 @@ def test_merge_addg(O):
 def test_noise_texture_range(O):
     nz = O.noise_tex(8)                                   # R8kVolRen3D_cpy.cpp:2421-2433
     assert nz.min() >= 127 and nz.max() <= 255            # (rand*.5 + .5 + 1/512)*255
+
+
+def test_clip_plane_on_a_voxel_face_equals_the_cropped_region():
+    """KAT for the orthogonal clip plane (NV20VolRen3D.cpp:251-327): a plane at vpos = fSize*k/N puts
+    the box face at voxel coordinate k - 1/2, which is where the brick region [0,k) ends; the two
+    frames can differ only in samples that lie exactly on the face."""
+    import _scenes as S
+    sc = S.make_scene("cfg3", n=24, size=40, steps=48, pose="rot", shade=1)
+    nx, ny, nz = sc.dims
+    for axis, k in ((1, 9), (4, 7), (5, 16)):
+        a = (axis - 1) // 2
+        vpos = [0.3, 0.3, 0.3]
+        vpos[a] = float(sc.fsize[a]) * k / sc.dims[a]
+        sc.clip, sc.region = (axis, tuple(vpos)), ((0, 0, 0), sc.dims)
+        clipped = sc.render()
+        sc.clip = None
+        g0, g1 = [0, 0, 0], list(sc.dims)
+        if axis % 2:
+            g1[a] = k
+        else:
+            g0[a] = k
+        sc.region = (tuple(g0), tuple(g1))
+        cropped = sc.render()
+        sc.region = ((0, 0, 0), sc.dims)
+        assert clipped[..., 3].max() > 0.05
+        assert np.abs(clipped - cropped).max() <= 1e-6

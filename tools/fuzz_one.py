@@ -32,7 +32,7 @@ def main():
             r = pkg.Renderer(0)
             r.set_shard(*sc.shard)
             sc.region = sortlast.shard_region(sc.dims, *sc.shard)
-        print("   rate %.3f eye %s trans %s frustum %s shard %s" % (sc.sample_rate, sc.eye, sc.trans, sc.frustum, sc.shard))
+        print("   rate %.3f eye %s trans %s frustum %s shard %s clip %s region %s" % (sc.sample_rate, sc.eye, sc.trans, sc.frustum, sc.shard, sc.clip, sc.region))
         try:
             print("   ->", F.one_case(r, sc, ""), flush=True)
         except Exception as e:

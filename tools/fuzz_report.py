@@ -47,7 +47,7 @@ def main():
         sc, kind, f32, dims = F.random_scene(rng)
         tag = "case %d: %s dims %s f32 %d %dx%d x%d rate %.2f shade %d eye %s trans %s frustum %s shard %s" % (
             case, kind, dims, f32, sc.width, sc.height, sc.steps, sc.sample_rate, sc.shade_mode, sc.eye, sc.trans,
-            tuple(round(float(x), 3) for x in sc.frustum), sc.shard)
+            tuple(round(float(x), 3) for x in sc.frustum), (sc.shard, sc.clip))
         r = R
         if sc.shard:
             r = pkg.Renderer(0)
