@@ -137,6 +137,13 @@ int smk_make_vgh_device(smk_ctx *ctx, const void *d_scalar, smk_dtype dtype, int
                         int sz, int compat, void *d_vgh_u8_or_null, void *d_vgh_f32_or_null);
 int smk_normals_vgh_device(smk_ctx *ctx, const void *d_vgh_u8, int nelts, int sx, int sy, int sz,
                            int blur, void *d_normals);
+/* replaces MetaVolume::hist2D (MetaVolume.cpp:1650-1688; caller TFWidgetRen::loadHist,
+ * TFWidgetRen1.cpp:660-700): the log-scaled joint histogram of the (value, gradient) bytes,
+ * hist[g*256 + v], 65536 bytes in HOST memory; bit-identical to the reference's, including its
+ * float bins that stop counting at 2^24.  nelts < 2 is refused as there.  _device: the volume
+ * [z][y][x][nelts] is already in device memory. */
+int smk_hist2d(smk_ctx *ctx, const smk_volume_desc *bricks, int n_bricks, int nelts, unsigned char *hist);
+int smk_hist2d_device(smk_ctx *ctx, const void *d_vol_u8, int nelts, int sx, int sy, int sz, unsigned char *hist);
 /* synthetic scalar test volume generated on the GPU (bench input; analytic, seed-stable):
  * kind 0 = noisy concentric shells (u8) */
 int smk_synth_volume_device(smk_ctx *ctx, int kind, unsigned seed, int sx, int sy, int sz,

@@ -107,6 +107,8 @@ def _proto(L):
                                C.c_void_p, C.c_void_p]
     L.orc_normals_vgh.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p]
+    L.orc_hist2d.argtypes = [C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]
+    L.orc_hist2d.restype = C.c_int
     L.orc_merge_addg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                  C.c_void_p]
     L.orc_brick_grid.argtypes = [C.c_int] * 4 + [P(C.c_int)]
@@ -341,6 +343,14 @@ def normals_vgh(vgh_u8, blur=False):
     out = np.zeros((sz, sy, sx, 3), np.uint8)
     lib().orc_normals_vgh(_p(np.ascontiguousarray(vgh_u8)), ne, sx, sy, sz, int(blur), _p(out))
     return out
+
+
+def hist2d(vol_u8):
+    """MetaVolume::hist2D: log-scaled joint (value, gradient) histogram [g][v] of a [z][y][x][nelts] volume"""
+    v = np.ascontiguousarray(vol_u8)
+    out = np.zeros((256, 256), np.uint8)
+    ok = lib().orc_hist2d(_p(v), v.shape[-1], v.size // v.shape[-1], _p(out))
+    return out if ok else None
 
 
 def merge_addg(fields_u8):

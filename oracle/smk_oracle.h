@@ -150,6 +150,7 @@ void orc_make_vgh(const void *in, int in_dtype, int sx, int sy, int sz, int comp
 
 /* MetaVolume::normalsVGH (MetaVolume.cpp:1274-1324): derivative3DVGH + blurV3D + scalebiasN.
  * data = u8 [..][nelts] (channel 0 differenced); out [..][3] */
+int orc_hist2d(const unsigned char *data, int nelts, long long nvox, unsigned char *hist);
 void orc_normals_vgh(const unsigned char *data, int nelts, int sx, int sy, int sz, int blur,
                      unsigned char *out);
 

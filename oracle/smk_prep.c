@@ -776,3 +776,30 @@ void orc_noise_tex(unsigned char *out, int n) {
   for (size_t q = 0; q < cnt; ++q)
     out[q] = uc_cast(((orc_rand() / (float)ORC_RAND_MAX * .5) + .5 + 1.0 / 512) * 255);
 }
+
+
+/* MetaVolume::hist2D (MetaVolume.cpp:1650-1688): joint histogram of the first two voxel bytes
+ * (value, gradient magnitude) over all sub-volumes, counted in FLOAT bins (so a bin stops growing
+ * at 2^24), then log-scaled: h = (float)log(count), max over h starting from 0,
+ * hist = (uchar)(h / max * 255).  Empty bins (log 0 = -inf) and the degenerate max = 0 case cast
+ * an infinity / NaN to uchar in the reference; here both give 0.  Returns 0 when nelts < 2
+ * ("this type of histogram is not implemented"). */
+int orc_hist2d(const unsigned char *data, int nelts, long long nvox, unsigned char *hist) {
+  if (nelts < 2 || !data) return 0;
+  float *ih = (float *)calloc(65536, sizeof(float));
+  for (long long i = 0; i < nvox; ++i) {
+    const unsigned char *d = data + i * nelts;
+    ih[d[0] + d[1] * 256] += 1;
+  }
+  float max = 0;
+  for (int i = 0; i < 65536; ++i) {
+    ih[i] = (float)log(ih[i]);
+    max = ih[i] > max ? ih[i] : max;
+  }
+  for (int i = 0; i < 65536; ++i) {
+    if (!(max > 0) || !isfinite(ih[i])) hist[i] = 0;
+    else hist[i] = (unsigned char)(ih[i] / (float)max * 255);
+  }
+  free(ih);
+  return 1;
+}

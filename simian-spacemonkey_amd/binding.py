@@ -16,7 +16,7 @@ _LIB = None
 
 ABI_SYMBOLS = [
     "smk_create", "smk_destroy", "smk_last_error", "smk_upload_volume",
-    "smk_upload_volume_device", "smk_set_shard", "smk_set_clip", "smk_shard_order", "smk_set_tlut1d",
+    "smk_upload_volume_device", "smk_set_shard", "smk_set_clip", "smk_hist2d", "smk_hist2d_device", "smk_shard_order", "smk_set_tlut1d",
     "smk_set_tf2d", "smk_set_tf3d", "smk_set_camera", "smk_set_shading", "smk_set_sampling",
     "smk_set_perturb", "smk_render", "smk_render_device", "smk_composite_over_device",
     "smk_make_vgh_device", "smk_normals_vgh_device", "smk_synth_volume_device",
@@ -105,6 +105,8 @@ def load_library():
                                       C.c_int, C.c_void_p, C.c_void_p]
     L.smk_normals_vgh_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_void_p]
+    L.smk_hist2d.argtypes = [C.c_void_p, C.POINTER(VolumeDesc), C.c_int, C.c_int, C.c_void_p]
+    L.smk_hist2d_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.smk_synth_volume_device.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p]
     L.smk_get_raycoef.argtypes = [C.c_void_p, P(RayCoef)]
@@ -329,6 +331,30 @@ class Renderer:
         sx, sy, sz = dims
         self._ck(self.L.smk_normals_vgh_device(self.ctx, d_vgh_u8, nelts, sx, sy, sz, int(blur),
                                                d_normals))
+
+    def hist2d_device(self, d_vol_u8, nelts, dims):
+        """log-scaled joint (value, gradient) histogram [g][v] of a device-resident u8 volume"""
+        sx, sy, sz = dims
+        out = np.zeros((256, 256), np.uint8)
+        self._ck(self.L.smk_hist2d_device(self.ctx, d_vol_u8, nelts, sx, sy, sz, _ptr(out)))
+        return out
+
+    def hist2d(self, data, grid=(1, 1, 1)):
+        """the same from host memory, brick by brick as MetaVolume holds it"""
+        data = np.ascontiguousarray(data, np.uint8)
+        nz, ny, nx, ne = data.shape
+        bricks = split_bricks((nx, ny, nz), (1.0, 1.0, 1.0), grid)
+        descs = (VolumeDesc * len(bricks))()
+        keep = []
+        for d, b in zip(descs, bricks):
+            (x0, y0, z0), (bx, by, bz) = b["ipos"], b["isize"]
+            sub = np.ascontiguousarray(data[z0:z0 + bz, y0:y0 + by, x0:x0 + bx])
+            keep.append(sub)
+            d.xiSize, d.yiSize, d.ziSize = bx, by, bz
+            d.data = _ptr(sub)
+        out = np.zeros((256, 256), np.uint8)
+        self._ck(self.L.smk_hist2d(self.ctx, descs, len(bricks), ne, _ptr(out)))
+        return out
 
     def synth_volume_device(self, kind, seed, dims, d_out):
         sx, sy, sz = dims

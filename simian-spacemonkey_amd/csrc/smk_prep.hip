@@ -15,6 +15,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
+#include <vector>
 
 #include "smk_internal.h"
 
@@ -327,6 +329,143 @@ extern "C" int smk_normals_vgh_device(smk_ctx *c, const void *d, int ne, int sx,
                      blur, (unsigned char *)out);
   PCHK(c, hipGetLastError());
   PCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------- 2-D histogram
+// MetaVolume::hist2D (MetaVolume.cpp:1650-1688): counts of (value, gradient) byte pairs.  HBM-bound
+// byte work: every workgroup keeps ALL 65536 bins in LDS as 16-bit counters (128 KB) and flushes
+// them to the global 32-bit bins after at most 61440 voxels, so no counter can overflow; a wave
+// whose 64 voxels fall into one bin (air, the common case) adds once instead of 64 times.
+#define SMK_HIST_CHUNK 61440  // voxels per flush (< 65536), a multiple of the block size
+
+__global__ __launch_bounds__(1024) void smk_k_hist2d(const unsigned char *vol, int nelts, size_t nvox, unsigned *bins) {
+  extern __shared__ unsigned h16[];  // 32768 words = 65536 halves
+  const size_t nchunks = (nvox + SMK_HIST_CHUNK - 1) / SMK_HIST_CHUNK;
+  for (size_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    for (int w = threadIdx.x; w < 32768; w += 1024) h16[w] = 0;
+    __syncthreads();
+    const size_t base = chunk * SMK_HIST_CHUNK;
+    for (int k = 0; k < SMK_HIST_CHUNK / 1024; ++k) {
+      const size_t i = base + (size_t)k * 1024 + threadIdx.x;
+      const bool ok = i < nvox;
+      unsigned key = 0;
+      if (ok) {
+        const unsigned char *d = vol + i * nelts;
+        key = (unsigned)d[0] | ((unsigned)d[1] << 8);
+      }
+      const unsigned long long live = __ballot(ok);
+      if (!live) continue;
+      const unsigned first = __builtin_amdgcn_readfirstlane(key);  // (of the first live lane)
+      if (__ballot(ok && key == first) == live) {
+        if (ok && (int)(threadIdx.x & 63) == __builtin_ctzll(live))
+          atomicAdd(&h16[first >> 1], (unsigned)__builtin_popcountll(live) << ((first & 1) * 16));
+      } else if (ok) {
+        atomicAdd(&h16[key >> 1], 1u << ((key & 1) * 16));
+      }
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < 32768; w += 1024) {
+      const unsigned x = h16[w];
+      if (x & 0xffffu) atomicAdd(&bins[2 * w], x & 0xffffu);
+      if (x >> 16) atomicAdd(&bins[2 * w + 1], x >> 16);
+    }
+    __syncthreads();
+  }
+}
+
+static int hist2d_count(smk_ctx *c, const unsigned char *d_vol, int nelts, size_t nvox, unsigned *d_bins) {
+  static bool attr = false;
+  if (!attr) {
+    PCHK(c, hipFuncSetAttribute((const void *)smk_k_hist2d, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    attr = true;
+  }
+  const size_t nchunks = (nvox + SMK_HIST_CHUNK - 1) / SMK_HIST_CHUNK;
+  const unsigned blocks = (unsigned)std::min<size_t>(nchunks, 256 * 4);
+  hipLaunchKernelGGL(smk_k_hist2d, dim3(blocks), dim3(1024), 128 * 1024, c->stream, d_vol, nelts, nvox, d_bins);
+  PCHK(c, hipGetLastError());
+  return 0;
+}
+
+// counts -> the reference's log-scaled bytes.  Its bins are floats incremented by 1: exact up to
+// 2^24, where they stop growing.
+static void hist2d_finish(const unsigned *counts, unsigned char *hist) {
+  std::vector<float> lg(65536);
+  float mx = 0;
+  for (int i = 0; i < 65536; ++i) {
+    const float ih = (float)std::min(counts[i], 16777216u);
+    lg[i] = (float)log((double)ih);
+    mx = lg[i] > mx ? lg[i] : mx;
+  }
+  for (int i = 0; i < 65536; ++i) hist[i] = (!(mx > 0) || !std::isfinite(lg[i])) ? 0 : (unsigned char)(lg[i] / mx * 255);
+}
+
+extern "C" int smk_hist2d_device(smk_ctx *c, const void *d_vol, int nelts, int sx, int sy, int sz, unsigned char *hist) {
+  if (!c) return 1;
+  PCHK(c, hipSetDevice(c->device));
+  if (!d_vol || !hist || sx < 1 || sy < 1 || sz < 1) {
+    c->err = "smk_hist2d_device: bad arguments";
+    return 1;
+  }
+  if (nelts < 2) {
+    c->err = "smk_hist2d_device: sorry this type of histogram is not implemented (needs value and gradient bytes)";
+    return 1;
+  }
+  unsigned *d_bins = nullptr;
+  PCHK(c, hipMalloc((void **)&d_bins, 65536 * sizeof(unsigned)));
+  int rc = 0;
+  std::vector<unsigned> counts(65536);
+  if (hipMemsetAsync(d_bins, 0, 65536 * sizeof(unsigned), c->stream) != hipSuccess ||
+      hist2d_count(c, (const unsigned char *)d_vol, nelts, (size_t)sx * sy * sz, d_bins) ||
+      hipMemcpyAsync(counts.data(), d_bins, 65536 * sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess) {
+    if (c->err.empty()) c->err = "smk_hist2d_device: HIP error";
+    rc = 1;
+  }
+  (void)hipFree(d_bins);
+  if (rc) return rc;
+  hist2d_finish(counts.data(), hist);
+  return 0;
+}
+
+// host bricks (the MetaVolume the application holds): staged through the device brick by brick
+extern "C" int smk_hist2d(smk_ctx *c, const smk_volume_desc *b, int nb, int nelts, unsigned char *hist) {
+  if (!c) return 1;
+  PCHK(c, hipSetDevice(c->device));
+  if (!b || nb < 1 || !hist) {
+    c->err = "smk_hist2d: bad arguments";
+    return 1;
+  }
+  if (nelts < 2) {
+    c->err = "smk_hist2d: sorry this type of histogram is not implemented (needs value and gradient bytes)";
+    return 1;
+  }
+  unsigned *d_bins = nullptr;
+  unsigned char *d_stage = nullptr;
+  size_t cap = 0;
+  PCHK(c, hipMalloc((void **)&d_bins, 65536 * sizeof(unsigned)));
+  int rc = hipMemsetAsync(d_bins, 0, 65536 * sizeof(unsigned), c->stream) != hipSuccess;
+  for (int i = 0; i < nb && !rc; ++i) {
+    const size_t nvox = (size_t)b[i].xiSize * b[i].yiSize * b[i].ziSize, bytes = nvox * nelts;
+    if (!b[i].data || !nvox) { c->err = "smk_hist2d: brick without data"; rc = 1; break; }
+    if (bytes > cap) {
+      if (d_stage) (void)hipFree(d_stage);
+      d_stage = nullptr;
+      if (hipMalloc((void **)&d_stage, bytes) != hipSuccess) { c->err = "smk_hist2d: out of device memory"; rc = 1; break; }
+      cap = bytes;
+    }
+    rc = hipMemcpyAsync(d_stage, b[i].data, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+         hist2d_count(c, d_stage, nelts, nvox, d_bins) || hipStreamSynchronize(c->stream) != hipSuccess;
+  }
+  std::vector<unsigned> counts(65536);
+  if (!rc) rc = hipMemcpy(counts.data(), d_bins, 65536 * sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess;
+  if (d_stage) (void)hipFree(d_stage);
+  (void)hipFree(d_bins);
+  if (rc) {
+    if (c->err.empty()) c->err = "smk_hist2d: HIP error";
+    return 1;
+  }
+  hist2d_finish(counts.data(), hist);
   return 0;
 }
 

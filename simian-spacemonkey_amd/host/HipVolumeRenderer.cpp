@@ -41,6 +41,22 @@ int HipVolumeRenderer::upload(Volume *v, int n) {
   return 0;
 }
 
+int HipVolumeRenderer::hist2D(unsigned char *hist) {
+  if (!ctx || !m_vol || !m_vol->volumes) return 0;
+  std::vector<smk_volume_desc> d((size_t)m_vol->numSubVols);
+  for (int i = 0; i < m_vol->numSubVols; ++i) {
+    const Volume &v = m_vol->volumes[i];
+    memset(&d[(size_t)i], 0, sizeof(smk_volume_desc));
+    d[(size_t)i].xiSize = v.xiSize; d[(size_t)i].yiSize = v.yiSize; d[(size_t)i].ziSize = v.ziSize;
+    d[(size_t)i].data = v.currentData;
+  }
+  if (smk_hist2d(ctx, d.data(), m_vol->numSubVols, m_vol->nelts, hist)) {
+    std::cerr << "MetaVolume::hist2D, " << smk_last_error(ctx) << std::endl;
+    return 0;  // the reference's "not implemented" return
+  }
+  return 1;
+}
+
 int HipVolumeRenderer::createVolume(int type, Volume *v) {
   if (type != VolRen3DExt) {  // VolumeRenderer.cpp:103-112: the other modes "not implemented"
     std::cerr << "texture mapping method is not implemented" << std::endl;

@@ -35,6 +35,8 @@ class HipVolumeRenderer {
   int ok() const { return ctx != nullptr && !failed; }
   smk_ctx *context() { return ctx; }
   void loadTransferTableRGBA();  // what TLUT::loadTransferTableRGBA did with the GL color table
+  // MetaVolume::hist2D (MetaVolume.cpp:1650-1688) for the TF window's background: 256x256 bytes, 1 = ok
+  int hist2D(unsigned char *hist);
 
  private:
   int upload(Volume *v, int n);

@@ -123,3 +123,47 @@ def test_random_sizes_bit_exact(R, O):
             R.normals_vgh_device(_dev(vgh).data_ptr(), 3, dims, blur, out.data_ptr())
             torch.cuda.synchronize()
             assert np.array_equal(out.cpu().numpy(), ref), (dims, blur)
+
+
+def test_hist2d_matches_the_reference_arithmetic(R, O):
+    """MetaVolume::hist2D on the GPU (16-bit LDS bins, flushed before they can overflow) against the
+    CPU restatement that counts in float bins as the reference does: every byte equal."""
+    import torch
+    rng = np.random.default_rng(17)
+    # a VGH-like volume: most voxels in a few bins (air), a tail spread over many
+    nz, ny, nx = 41, 53, 67
+    vgh = np.zeros((nz, ny, nx, 3), np.uint8)
+    vgh[..., 0] = np.clip(rng.normal(20, 6, (nz, ny, nx)), 0, 255)
+    vgh[..., 1] = np.clip(rng.exponential(9, (nz, ny, nx)), 0, 255)
+    vgh[10:30, 10:40, 5:60, 0] = rng.integers(0, 256, (20, 30, 55))
+    vgh[10:30, 10:40, 5:60, 1] = rng.integers(0, 256, (20, 30, 55))
+    vgh[:8] = (3, 0, 85)                                   # a uniform slab: whole waves in one bin
+    ref = O.hist2d(vgh)
+    got = R.hist2d_device(_dev(vgh).data_ptr(), 3, (nx, ny, nz))
+    assert ref.max() == 255 and np.count_nonzero(ref) > 1000
+    assert np.array_equal(got, ref)
+    assert np.array_equal(R.hist2d(vgh, grid=(1, 1, 1)), ref)
+    # bricked host volume: MetaVolume::brick drops remainder voxels, so compare on what the bricks hold
+    even = np.ascontiguousarray(vgh[:40, :52, :66])
+    assert np.array_equal(R.hist2d(even, grid=(2, 2, 2)), O.hist2d(even))
+    two = np.ascontiguousarray(vgh[..., :2])               # (value, gradient) pairs only
+    assert np.array_equal(R.hist2d_device(_dev(two).data_ptr(), 2, (nx, ny, nz)), O.hist2d(two))
+    with pytest.raises(Exception, match="not implemented"):
+        R.hist2d_device(_dev(vgh[..., :1]).data_ptr(), 1, (nx, ny, nz))
+    assert O.hist2d(np.ascontiguousarray(vgh[..., :1])) is None
+
+
+def test_hist2d_float_bins_stop_at_two_to_the_24(R, O):
+    """the reference counts in float: a bin holding more than 2^24 voxels reads 2^24.  A 272^3
+    volume with 19 M voxels in one bin and 1.1 M in another pins that on both sides."""
+    import torch
+    n = 272
+    vol = torch.zeros((n, n, n, 2), dtype=torch.uint8, device="cuda")
+    vol[:15] = torch.tensor([7, 9], dtype=torch.uint8, device="cuda")
+    got = R.hist2d_device(vol.data_ptr(), 2, (n, n, n))
+    ref = O.hist2d(vol.cpu().numpy())
+    assert np.array_equal(got, ref)
+    big, small = (n - 15) * n * n, 15 * n * n
+    assert big > 2 ** 24
+    want_small = int(np.float32(np.float32(np.log(float(small))) / np.float32(np.log(float(2 ** 24))) * 255))
+    assert got[0, 0] == 255 and got[9, 7] == want_small and np.count_nonzero(got) == 2

@@ -262,3 +262,17 @@ def test_clip_plane_on_a_voxel_face_equals_the_cropped_region():
         sc.region = ((0, 0, 0), sc.dims)
         assert clipped[..., 3].max() > 0.05
         assert np.abs(clipped - cropped).max() <= 1e-6
+
+
+def test_hist2d_log_scaling_known_answers():
+    """MetaVolume::hist2D (MetaVolume.cpp:1650-1688): bins holding 1, 2, 8 and 64 voxels -> log counts
+    0, ln2, 3ln2, 6ln2 -> bytes 0, (uchar)(255/6) = 42, (uchar)(255/2) = 127, 255; empty bins 0."""
+    import oracle as O
+    vox = [(10, 20)] * 1 + [(11, 20)] * 2 + [(12, 21)] * 8 + [(200, 3)] * 64
+    v = np.zeros((1, 1, len(vox), 3), np.uint8)
+    v[0, 0, :, 0] = [a for a, _ in vox]
+    v[0, 0, :, 1] = [b for _, b in vox]
+    h = O.hist2d(v)
+    assert (h[20, 10], h[20, 11], h[21, 12], h[3, 200]) == (0, 42, 127, 255)
+    assert np.count_nonzero(h) == 3
+    assert O.hist2d(v[..., :1]) is None            # "this type of histogram is not implemented"
