@@ -112,6 +112,11 @@ int smk_set_sampling(smk_ctx *ctx, float sample_rate, int steps, float gamma, in
  * on one side of an axis-aligned plane through vpos (volume space, the units of fPos/fSize).
  * oaxis = VolRenMajorAxis: 1 X+ (x <= vpos.x stays), 2 X-, 3 Y+, 4 Y-, 5 Z+, 6 Z-.  on = 0: off. */
 int smk_set_clip(smk_ctx *ctx, int on, int oaxis, const float vpos[3]);
+/* replaces the clip widget's free mode: glClipPlane(GL_CLIP_PLANE5, {0,0,-1,0}) specified under the
+ * modelview wmv * T(clip.pos) * clip.xform (NV20VolRen3D.cpp:346-357; R8kVolRen3D.cpp:780-794).
+ * plane_eye = the eye-space plane OpenGL stores for that call ({0,0,-1,0} times the inverse of that
+ * matrix); a sample stays when plane_eye . (x_eye, 1) >= 0.  Frames with it run on the gather kernel. */
+int smk_set_clip_plane(smk_ctx *ctx, int on, const double plane_eye[4]);
 int smk_set_perturb(smk_ctx *ctx, const unsigned char *noise_rgba, int n, const float w[4],
                     const float s[4]);
 

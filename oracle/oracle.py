@@ -36,7 +36,8 @@ class Volume(C.Structure):
                 ("dtype", C.c_int), ("data", C.c_void_p), ("grad", C.c_void_p),
                 ("fx", C.c_float), ("fy", C.c_float), ("fz", C.c_float),
                 ("g0", C.c_int * 3), ("g1", C.c_int * 3),
-                ("clip_axis", C.c_int), ("clip_vpos", C.c_float * 3)]
+                ("clip_axis", C.c_int), ("clip_vpos", C.c_float * 3),
+                ("cplane_on", C.c_int), ("cplane", C.c_float * 4)]
 
 
 class Classify(C.Structure):
@@ -193,6 +194,7 @@ class Scene:
         self.noise = None
         self.pert_w, self.pert_s = (0, 0, 0, 0), (0.2, 2.1, 4.5, 8.7)   # gluvvui.cpp:213-267
         self.mv_override = None
+        self.clip_plane = None  # free clip plane, eye space (what glClipPlane stores): keep plane . (x_eye,1) >= 0
         self.clip = None        # (axis 1..6 = X+ X- Y+ Y- Z+ Z-, vpos[3] in volume space): gluvv.clip, ortho mode
 
     def mv(self):
@@ -213,6 +215,12 @@ class Scene:
         v.g1[:] = self.region[1]
         v.clip_axis = self.clip[0] if self.clip else 0
         v.clip_vpos[:] = self.clip[1] if self.clip else (0, 0, 0)
+        v.cplane_on = 1 if self.clip_plane is not None else 0
+        if self.clip_plane is not None:
+            out = (C.c_float * 4)()
+            lib().orc_clip_plane_voxel((C.c_double * 4)(*[float(x) for x in self.clip_plane]), (C.c_double * 16)(*self.mv()),
+                                       (C.c_float * 3)(*[float(f) for f in self.fsize]), (C.c_int * 3)(*self.dims), out)
+            v.cplane[:] = list(out)
         return v
 
     def c_classify(self):

@@ -399,6 +399,22 @@ static int shade_sample(const orc_volume *v, const orc_classify *tf, const orc_s
   return 1;
 }
 
+/* Free clip plane (NV20VolRen3D.cpp:346-357): glClipPlane keeps eye-space points with
+ * plane_eye . (x,1) >= 0.  With eye = MV * model and model = (p + 1/2)/N * fSize the same test in
+ * voxel coordinates has the coefficients below (double arithmetic, rounded once to float). */
+void orc_clip_plane_voxel(const double plane_eye[4], const double mv[16], const float fsize[3], const int N[3], float out[4]) {
+  double pm[4];
+  for (int k = 0; k < 4; ++k)
+    pm[k] = plane_eye[0] * mv[4 * k + 0] + plane_eye[1] * mv[4 * k + 1] + plane_eye[2] * mv[4 * k + 2] + plane_eye[3] * mv[4 * k + 3];
+  double w = pm[3];
+  for (int a = 0; a < 3; ++a) {
+    const double sc = (double)fsize[a] / (double)N[a];
+    out[a] = (float)(pm[a] * sc);
+    w += pm[a] * sc * 0.5;
+  }
+  out[3] = (float)w;
+}
+
 /* ------------------------------------------------------------ one ray */
 
 static long long march_pixel(const orc_volume *v, const orc_classify *tf, const orc_shade *sh,
@@ -448,6 +464,7 @@ static long long march_pixel(const orc_volume *v, const orc_classify *tf, const 
       if (!(p[a] >= lo[a] && (p[a] < hi[a] || (top[a] && p[a] <= hi[a])))) in = 0;
     }
     if (!in) continue;
+    if (v->cplane_on && !(fmaf(p[0], v->cplane[0], fmaf(p[1], v->cplane[1], fmaf(p[2], v->cplane[2], v->cplane[3]))) >= 0.0f)) continue;
     ++inside;
     float src[4];
     if (!shade_sample(v, tf, sh, pt, p[0], p[1], p[2], src)) continue;

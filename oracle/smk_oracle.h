@@ -36,6 +36,8 @@ typedef struct {
   int g0[3], g1[3];          /* region [g0,g1) in voxel indices (x,y,z)                    */
   int clip_axis;             /* orthogonal clip plane: 0 off, 1..6 = X+ X- Y+ Y- Z+ Z- (VolRenMajorAxis, gluvv.h:136-144) */
   float clip_vpos[3];        /* its position in volume space (gluvv.clip.vpos)             */
+  int cplane_on;             /* free clip plane (glClipPlane): keep fma-chain(cplane . (p,1)) >= 0, voxel coordinates */
+  float cplane[4];
 } orc_volume;
 
 enum { ORC_TF_1D = 0, ORC_TF_2D = 1, ORC_TF_3D = 2 };
@@ -150,6 +152,7 @@ void orc_make_vgh(const void *in, int in_dtype, int sx, int sy, int sz, int comp
 
 /* MetaVolume::normalsVGH (MetaVolume.cpp:1274-1324): derivative3DVGH + blurV3D + scalebiasN.
  * data = u8 [..][nelts] (channel 0 differenced); out [..][3] */
+void orc_clip_plane_voxel(const double plane_eye[4], const double mv[16], const float fsize[3], const int N[3], float out[4]);
 int orc_hist2d(const unsigned char *data, int nelts, long long nvox, unsigned char *hist);
 void orc_normals_vgh(const unsigned char *data, int nelts, int sx, int sy, int sz, int blur,
                      unsigned char *out);

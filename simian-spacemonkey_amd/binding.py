@@ -16,7 +16,7 @@ _LIB = None
 
 ABI_SYMBOLS = [
     "smk_create", "smk_destroy", "smk_last_error", "smk_upload_volume",
-    "smk_upload_volume_device", "smk_set_shard", "smk_set_clip", "smk_hist2d", "smk_hist2d_device", "smk_shard_order", "smk_set_tlut1d",
+    "smk_upload_volume_device", "smk_set_shard", "smk_set_clip", "smk_set_clip_plane", "smk_hist2d", "smk_hist2d_device", "smk_shard_order", "smk_set_tlut1d",
     "smk_set_tf2d", "smk_set_tf3d", "smk_set_camera", "smk_set_shading", "smk_set_sampling",
     "smk_set_perturb", "smk_render", "smk_render_device", "smk_composite_over_device",
     "smk_make_vgh_device", "smk_normals_vgh_device", "smk_synth_volume_device",
@@ -87,6 +87,7 @@ def load_library():
         getattr(L, n).argtypes = [C.c_void_p, P(VolumeDesc), C.c_int, C.c_int, C.c_int, C.c_int]
     L.smk_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.smk_set_clip.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.smk_set_clip_plane.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     L.smk_shard_order.argtypes = [C.c_void_p, P(C.c_int)]
     L.smk_set_tlut1d.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.smk_set_tf2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -257,6 +258,13 @@ class Renderer:
             self._ck(self.L.smk_set_clip(self.ctx, 0, 0, None))
         else:
             self._ck(self.L.smk_set_clip(self.ctx, 1, int(axis), _fa(vpos)))
+
+    def set_clip_plane(self, plane_eye):
+        """free clip plane in eye space (what glClipPlane stores); None switches it off"""
+        if plane_eye is None:
+            self._ck(self.L.smk_set_clip_plane(self.ctx, 0, None))
+        else:
+            self._ck(self.L.smk_set_clip_plane(self.ctx, 1, (C.c_double * 4)(*[float(v) for v in plane_eye])))
 
     def set_perturb(self, noise, w, s):
         if noise is None:

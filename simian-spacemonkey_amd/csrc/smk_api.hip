@@ -297,6 +297,18 @@ extern "C" int smk_set_clip(smk_ctx *c, int on, int oaxis, const float *vpos) {
   return 0;
 }
 
+extern "C" int smk_set_clip_plane(smk_ctx *c, int on, const double *plane_eye) {
+  if (!c) return 1;
+  if (!on) {
+    c->cplane_on = 0;
+    return 0;
+  }
+  if (!plane_eye) FAIL(c, "smk_set_clip_plane: plane missing");
+  c->cplane_on = 1;
+  for (int k = 0; k < 4; ++k) c->cplane_eye[k] = plane_eye[k];
+  return 0;
+}
+
 extern "C" int smk_set_shard(smk_ctx *c, int rank, int nranks) {
   if (!c) return 1;
   if (!(nranks == 1 || nranks == 2 || nranks == 4 || nranks == 8)) FAIL(c, "smk_set_shard: nranks must be 1,2,4 or 8");
@@ -782,6 +794,23 @@ static int build_params(smk_ctx *c, RenderParams &P) {
     }
   }
   for (int a = 0; a < 3; ++a) P.hin[a] = P.top[a] ? P.hi[a] : nextafterf(P.hi[a], -INFINITY);
+  // free clip plane: eye-space plane -> voxel coordinates.  eye = MV * model, model = (p + 1/2)/N * fSize
+  // (same operations in the same order as the CPU checker's orc_clip_plane_voxel)
+  P.cplane_on = c->cplane_on;
+  for (int k = 0; k < 4; ++k) P.cplane[k] = 0.0f;
+  if (c->cplane_on) {
+    double pm[4];  // plane in model space: row vector times MV (column-major)
+    for (int k = 0; k < 4; ++k)
+      pm[k] = c->cplane_eye[0] * c->mv[4 * k + 0] + c->cplane_eye[1] * c->mv[4 * k + 1] + c->cplane_eye[2] * c->mv[4 * k + 2] +
+              c->cplane_eye[3] * c->mv[4 * k + 3];
+    double w = pm[3];
+    for (int a = 0; a < 3; ++a) {
+      const double sc = (double)c->fsize[a] / (double)c->N[a];
+      P.cplane[a] = (float)(pm[a] * sc);
+      w += pm[a] * sc * 0.5;
+    }
+    P.cplane[3] = (float)w;
+  }
   P.nelts = c->nelts;
   P.n_in_w = (c->dtype == SMK_F32 && c->nelts <= 3) ? 1 : 0;
   P.tlut = c->d_tlut;

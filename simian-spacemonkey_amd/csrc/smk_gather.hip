@@ -76,6 +76,8 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
               (p1 >= P.lo[1] && (p1 < P.hi[1] || (P.top[1] && p1 <= P.hi[1]))) &&
               (p2 >= P.lo[2] && (p2 < P.hi[2] || (P.top[2] && p2 <= P.hi[2])));
     if (!in) continue;
+    // free clip plane (glClipPlane semantics, NV20VolRen3D.cpp:346-357): fragments on its negative side do not exist
+    if (P.cplane_on && !(__fmaf_rn(p0, P.cplane[0], __fmaf_rn(p1, P.cplane[1], __fmaf_rn(p2, P.cplane[2], P.cplane[3]))) >= 0.0f)) continue;
 
     if (P.pert_on) {
       // tc' = tc + sum w_m (noise(tc s_m) - .5)   (R8kVolRen3D_cpy.cpp:1590-1595, 3462-3490)

@@ -25,6 +25,8 @@ struct RenderParams {
   int D[3];             // stored dims (region + halo)
   float lo[3], hi[3];   // region in voxel coordinates: [g0-.5, g1-.5)
   int top[3];           // region touches the volume's top face on this axis (inclusive)
+  int cplane_on;        // free clip plane: a sample stays when fma-chain(cplane . (p,1)) >= 0 (voxel coordinates)
+  float cplane[4];
   float hin[3];         // largest coordinate that is inside: hi on a top face, else the float below hi
   float invN[3];
   int nelts;
@@ -102,6 +104,8 @@ struct smk_ctx {
   int halo = 1;
   int clip_axis = 0;  // orthogonal clip plane: 0 off, 1..6 = X+ X- Y+ Y- Z+ Z-
   float clip_vpos[3] = {0, 0, 0};
+  int cplane_on = 0;  // free clip plane (glClipPlane), eye space
+  double cplane_eye[4] = {0, 0, 0, 0};
   void *d_vox = nullptr;
   void *d_vox_x = nullptr;  // x-major copy [x][z][y] for views whose principal axis is x (lazy)
   std::string slab_why;     // why the last frame fell back to the gather kernel ("" if it did not)

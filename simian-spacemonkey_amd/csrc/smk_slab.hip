@@ -1100,6 +1100,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
   if (Q.perm == 0) { Q.strideV = P.D[0]; Q.strideS = (long long)P.D[0] * P.D[1]; Q.vox = vox_native; }
   else if (Q.perm == 1) { Q.strideV = (long long)P.D[0] * P.D[1]; Q.strideS = P.D[0]; Q.vox = vox_native; }
   else { Q.strideV = P.D[1]; Q.strideS = (long long)P.D[1] * P.D[2]; Q.vox = vox_xmajor; }  // [x][z][y]
+  if (P.cplane_on) { *why = "free clip plane (a per-sample half-space test: gather kernel)"; return hipErrorNotSupported; }
   // an empty region (a clip plane outside a shard's box): the gather kernel's explicit comparisons
   // render it as nothing; the median-of-three membership test here needs lo <= hi
   for (int a = 0; a < 3; ++a)

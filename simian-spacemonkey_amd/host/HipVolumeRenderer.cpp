@@ -7,6 +7,9 @@
 #include <iostream>
 
 static void build_modelview(double mv[16]);  // LookAt * T(trans) * R(xform) * T(-size/2)
+static void build_world_modelview(double mv[16]);
+static void mul(double o[16], const double a[16], const double b[16]);
+static void translate(double m[16], double x, double y, double z);
 
 HipVolumeRenderer::HipVolumeRenderer(MetaVolume *vm, int, int device) : ctx(nullptr), m_vol(vm), tlut(nullptr), failed(0) {
   int err = 0;
@@ -144,6 +147,21 @@ void HipVolumeRenderable::draw() {
   }
   // clip-plane widget, orthogonal mode (NV20VolRen3D::setupClips, NV20VolRen3D.cpp:251-327)
   smk_set_clip(c, gluvv.clip.on && gluvv.clip.ortho, (int)gluvv.clip.oaxis, gluvv.clip.vpos);
+  // free mode: glClipPlane(GL_CLIP_PLANE5, {0,0,-1,0}) under wmv * T(clip.pos) * clip.xform (:346-357).
+  // That matrix K is rigid, so the eye-space plane GL stores, zup * K^-1, is (-z_K, z_K . t_K): normal
+  // against the widget's local z axis, through its origin.
+  if (gluvv.clip.on && !gluvv.clip.ortho) {
+    double wmv[16], t[16], x[16], k[16];
+    build_world_modelview(wmv);
+    translate(t, gluvv.clip.pos[0], gluvv.clip.pos[1], gluvv.clip.pos[2]);
+    for (int i = 0; i < 16; ++i) x[i] = gluvv.clip.xform[i];
+    mul(k, wmv, t);
+    mul(k, k, x);
+    const double plane[4] = {-k[8], -k[9], -k[10], k[8] * k[12] + k[9] * k[13] + k[10] * k[14]};
+    smk_set_clip_plane(c, 1, plane);
+  } else {
+    smk_set_clip_plane(c, 0, nullptr);
+  }
   smk_shade sm = SMK_SHADE_NONE;
   if (gluvv.shade == gluvvShadeDiff) sm = SMK_SHADE_R8K_DIFF;
   if (gluvv.shade == gluvvShadeDSpec) sm = SMK_SHADE_R8K_DSPEC;
@@ -167,6 +185,20 @@ static void translate(double m[16], double x, double y, double z) {
   memset(m, 0, 16 * sizeof(double));
   m[0] = m[5] = m[10] = m[15] = 1;
   m[12] = x; m[13] = y; m[14] = z;
+}
+static void build_world_modelview(double mv[16]) {  // gluLookAt(eye, at, up): the "wmv" the clip widget lives in
+  const float *e = gluvv.env.eye, *a = gluvv.env.at, *u = gluvv.env.up;
+  double f[3] = {a[0] - e[0], a[1] - e[1], a[2] - e[2]};
+  double fl = sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]);
+  for (double &x : f) x /= fl;
+  double s[3] = {f[1] * u[2] - f[2] * u[1], f[2] * u[0] - f[0] * u[2], f[0] * u[1] - f[1] * u[0]};
+  double sl = sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]);
+  for (double &x : s) x /= sl;
+  double uu[3] = {s[1] * f[2] - s[2] * f[1], s[2] * f[0] - s[0] * f[2], s[0] * f[1] - s[1] * f[0]};
+  double la[16] = {s[0], uu[0], -f[0], 0, s[1], uu[1], -f[1], 0, s[2], uu[2], -f[2], 0, 0, 0, 0, 1};
+  double t[16];
+  translate(t, -e[0], -e[1], -e[2]);
+  mul(mv, la, t);
 }
 static void build_modelview(double mv[16]) {
   const float *e = gluvv.env.eye, *a = gluvv.env.at, *u = gluvv.env.up;

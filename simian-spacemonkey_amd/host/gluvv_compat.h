@@ -85,7 +85,13 @@ struct gluvvGlobal {
     float gamma = 1;
   } volren;
   struct { int ptexsz[3] = {256, 256, 1}; int numelts = 4; } tf;
-  struct { int on = 0, ortho = 1; VolRenMajorAxis oaxis = VolRenAxisXPos; float vpos[3] = {0, 0, 0}; } clip;  // gluvvClip (gluvv.h:163-175), the fields the renderer reads
+  struct {
+    int on = 0, ortho = 1;
+    VolRenMajorAxis oaxis = VolRenAxisXPos;
+    float vpos[3] = {0, 0, 0};   // plane position in volume space (orthogonal mode)
+    float pos[3] = {0, 0, 0};    // plane position in world space (free mode)
+    float xform[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};  // its orientation
+  } clip;  // gluvvClip (gluvv.h:163-175), the fields the renderer reads
   struct { int on = 0; float weights[10] = {.2f, 0, 0, 0}, scales[10] = {.2f, 2.1f, 4.5f, 8.7f}; } pert;
   int picking = 0;
   int reblend = 0;

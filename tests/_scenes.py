@@ -133,6 +133,7 @@ def push_scene(r, sc, grid=(1, 1, 1), upload=True):
     else:
         r.set_tf3d(sc.tf3d)
     r.set_clip(*(sc.clip if getattr(sc, "clip", None) else (0, None)))
+    r.set_clip_plane(getattr(sc, "clip_plane", None))
     r.set_camera(sc.mv(), sc.frustum, (sc.znear, 20.0), sc.width, sc.height)
     r.set_sampling(sc.sample_rate, sc.steps, 1.0, 1)
     mode = {0: "none", 1: "r8k" if sc.use_spec else "r8k_diff", 2: "nv20" if sc.use_spec else "nv20_diff"}[sc.shade_mode]

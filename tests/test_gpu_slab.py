@@ -250,3 +250,31 @@ def test_clip_plane_outside_a_shard_leaves_it_empty(gpu_renderer_factory):
             r.render()
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("pose", ["rot", "z-"])
+def test_free_clip_plane_runs_on_the_gather_kernel(R, pose):
+    """gluvv.clip in its free mode = glClipPlane under the widget's matrix (NV20VolRen3D.cpp:346-357):
+    a per-sample half-space test in eye space.  The gather kernel takes it; the slice-ring kernel,
+    whose rays know their inside interval from an axis-aligned box, declines."""
+    sc = make_scene("cfg2", n=32, size=64, steps=72, pose=pose, f32=True, shade=1)
+    whole = sc.render()
+    n = np.array([0.35, -0.2, -0.9])
+    n /= np.linalg.norm(n)
+    mv = np.array(sc.mv(), np.float64).reshape(4, 4).T   # column-major -> rows
+    centre = mv @ np.array([float(sc.fsize[0]) / 2, float(sc.fsize[1]) / 2, float(sc.fsize[2]) / 2, 1.0])
+    sc.clip_plane = (n[0], n[1], n[2], -float(n @ centre[:3]) + 0.03)   # through (almost) the volume's middle
+    ref = sc.render()
+    assert np.abs(ref - whole).max() > 0.02 and ref[..., 3].max() > 0.05
+    push_scene(R, sc)
+    R.set_option("kernel", 0)
+    img = R.render()
+    assert R.last_frame_info()[0] == 1
+    assert np.abs(img - ref).max() <= TOL
+    R.set_option("kernel", 2)
+    with pytest.raises(Exception, match="free clip plane"):
+        R.render()
+    R.set_option("kernel", 0)
+    sc.clip_plane = None
+    a, b = _both(R, sc, upload=False)
+    assert np.array_equal(a, b) and np.abs(b - whole).max() <= TOL
