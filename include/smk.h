@@ -142,6 +142,13 @@ int smk_make_vgh_device(smk_ctx *ctx, const void *d_scalar, smk_dtype dtype, int
                         int sz, int compat, void *d_vgh_u8_or_null, void *d_vgh_f32_or_null);
 int smk_normals_vgh_device(smk_ctx *ctx, const void *d_vgh_u8, int nelts, int sx, int sy, int sz,
                            int blur, void *d_normals);
+/* replaces MetaVolume::mergeMV with addG (MetaVolume.cpp:1109-1268; AGradArb VectorMath.h:945-1004,
+ * GMag :1010-1030, scalebiasN :1133-1148): nf (1..3) co-registered scalar fields, interleaved
+ * [z][y][x][nf] u8 -> d_out [z][y][x][nf+1] with the magnitude of the SUMMED per-field gradient as
+ * last element, and optionally the normal bytes [z][y][x][3] of that gradient.  Device pointers;
+ * bytes identical to the reference arithmetic. */
+int smk_merge_fields_device(smk_ctx *ctx, const void *d_fields_u8, int nf, int sx, int sy, int sz,
+                            void *d_out, void *d_normals_or_null);
 /* replaces MetaVolume::hist2D (MetaVolume.cpp:1650-1688; caller TFWidgetRen::loadHist,
  * TFWidgetRen1.cpp:660-700): the log-scaled joint histogram of the (value, gradient) bytes,
  * hist[g*256 + v], 65536 bytes in HOST memory; bit-identical to the reference's, including its

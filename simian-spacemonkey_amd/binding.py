@@ -16,7 +16,7 @@ _LIB = None
 
 ABI_SYMBOLS = [
     "smk_create", "smk_destroy", "smk_last_error", "smk_upload_volume",
-    "smk_upload_volume_device", "smk_set_shard", "smk_set_clip", "smk_set_clip_plane", "smk_hist2d", "smk_hist2d_device", "smk_shard_order", "smk_set_tlut1d",
+    "smk_upload_volume_device", "smk_set_shard", "smk_set_clip", "smk_set_clip_plane", "smk_hist2d", "smk_hist2d_device", "smk_merge_fields_device", "smk_shard_order", "smk_set_tlut1d",
     "smk_set_tf2d", "smk_set_tf3d", "smk_set_camera", "smk_set_shading", "smk_set_sampling",
     "smk_set_perturb", "smk_render", "smk_render_device", "smk_composite_over_device",
     "smk_make_vgh_device", "smk_normals_vgh_device", "smk_synth_volume_device",
@@ -106,6 +106,7 @@ def load_library():
                                       C.c_int, C.c_void_p, C.c_void_p]
     L.smk_normals_vgh_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_void_p]
+    L.smk_merge_fields_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.smk_hist2d.argtypes = [C.c_void_p, C.POINTER(VolumeDesc), C.c_int, C.c_int, C.c_void_p]
     L.smk_hist2d_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.smk_synth_volume_device.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_int, C.c_int,
@@ -339,6 +340,10 @@ class Renderer:
         sx, sy, sz = dims
         self._ck(self.L.smk_normals_vgh_device(self.ctx, d_vgh_u8, nelts, sx, sy, sz, int(blur),
                                                d_normals))
+
+    def merge_fields_device(self, d_fields, nf, dims, d_out, d_normals=None):
+        sx, sy, sz = dims
+        self._ck(self.L.smk_merge_fields_device(self.ctx, d_fields, nf, sx, sy, sz, d_out, d_normals))
 
     def hist2d_device(self, d_vol_u8, nelts, dims):
         """log-scaled joint (value, gradient) histogram [g][v] of a device-resident u8 volume"""

@@ -332,6 +332,79 @@ extern "C" int smk_normals_vgh_device(smk_ctx *c, const void *d, int ne, int sx,
   return 0;
 }
 
+// ------------------------------------------------------------------------------- multi-field merge
+// MetaVolume::mergeMV with addG (MetaVolume.cpp:1109-1268): nf scalar fields interleaved
+// [z][y][x][nf] -> [z][y][x][nf+1] with G = |sum over fields of un-normalised central differences|
+// (AGradArb, VectorMath.h:945-1004; 0 on the 1-voxel border) scaled by the volume's maximum to
+// 0..255 (GMag, :1010-1030), and the normal bytes of that summed gradient (scalebiasN).
+__device__ __forceinline__ void merge_grad(const unsigned char *in, int nf, int sx, int sy, int sz, int i, int j, int k, float g[3]) {
+  g[0] = g[1] = g[2] = 0.f;
+  if (is_border(sx, sy, sz, i, j, k)) return;
+  const size_t sxy = (size_t)sx * sy, o = (size_t)i * sxy + (size_t)j * sx + k;
+  for (int e = 0; e < nf; ++e) {  // byte differences and their sums are exact in float
+    g[0] += (float)in[(o + 1) * nf + e] - (float)in[(o - 1) * nf + e];
+    g[1] += (float)in[(o + sx) * nf + e] - (float)in[(o - sx) * nf + e];
+    g[2] += (float)in[(o + sxy) * nf + e] - (float)in[(o - sxy) * nf + e];
+  }
+}
+
+__global__ __launch_bounds__(256) void smk_k_merge_max(const unsigned char *in, int nf, int sx, int sy, int sz, int *omax) {
+  const size_t n = (size_t)sx * sy * sz;
+  int m = 0;  // f2o(0.0f): magnitudes are >= 0
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    int k = (int)(t % sx), j = (int)((t / sx) % sy), i = (int)(t / ((size_t)sx * sy));
+    float g[3];
+    merge_grad(in, nf, sx, sy, sz, i, j, k, g);
+    m = max(m, f2o(sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2])));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(omax, m);
+}
+
+__global__ __launch_bounds__(256) void smk_k_merge_write(const unsigned char *in, int nf, int sx, int sy, int sz, const int *omax,
+                                                         unsigned char *out, unsigned char *nrm) {
+  const size_t n = (size_t)sx * sy * sz;
+  const float maxm = o2f(*omax);
+  const int ne = nf + 1;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    int k = (int)(t % sx), j = (int)((t / sx) % sy), i = (int)(t / ((size_t)sx * sy));
+    float g[3];
+    merge_grad(in, nf, sx, sy, sz, i, j, k, g);
+    for (int e = 0; e < nf; ++e) out[t * ne + e] = in[t * nf + e];
+    const float mag = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+    const double q = (double)(mag / maxm) * 255.0;  // (uchar)(mag/max*255.0): float quotient, double product
+    out[t * ne + nf] = (q > -2147483649.0 && q < 2147483648.0) ? (unsigned char)((int)q & 0xff) : 0;
+    if (nrm) nrm_store(g, nrm + t * 3);
+  }
+}
+
+extern "C" int smk_merge_fields_device(smk_ctx *c, const void *d_fields, int nf, int sx, int sy, int sz, void *d_out,
+                                       void *d_normals) {
+  if (!c) return 1;
+  PCHK(c, hipSetDevice(c->device));
+  if (!d_fields || !d_out || nf < 1 || nf > 3 || sx < 3 || sy < 3 || sz < 3) {
+    c->err = "smk_merge_fields_device: bad arguments (1..3 fields, dims >= 3)";
+    return 1;
+  }
+  int *d_max = nullptr;
+  PCHK(c, hipMalloc((void **)&d_max, sizeof(int)));
+  const size_t n = (size_t)sx * sy * sz;
+  const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
+  int rc = hipMemsetAsync(d_max, 0, sizeof(int), c->stream) != hipSuccess;
+  if (!rc) {
+    hipLaunchKernelGGL(smk_k_merge_max, dim3(blocks), dim3(256), 0, c->stream, (const unsigned char *)d_fields, nf, sx, sy, sz, d_max);
+    hipLaunchKernelGGL(smk_k_merge_write, dim3(blocks), dim3(256), 0, c->stream, (const unsigned char *)d_fields, nf, sx, sy, sz,
+                       d_max, (unsigned char *)d_out, (unsigned char *)d_normals);
+    rc = hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess;
+  }
+  (void)hipFree(d_max);
+  if (rc) {
+    c->err = "smk_merge_fields_device: HIP error";
+    return 1;
+  }
+  return 0;
+}
+
 // ------------------------------------------------------------------------------- 2-D histogram
 // MetaVolume::hist2D (MetaVolume.cpp:1650-1688): counts of (value, gradient) byte pairs.  HBM-bound
 // byte work: every workgroup keeps ALL 65536 bins in LDS as 16-bit counters (128 KB) and flushes

@@ -101,3 +101,49 @@ def test_empty_and_degenerate(R):
     sc = make_scene("cfg2")
     sc.steps = 1
     _check(R, sc, tol=1e-6) if sc.render()[..., 3].max() > 0.05 else None
+
+
+@pytest.mark.parametrize("world", [1, 8])
+def test_cfg5_multi_field_dense_tf_and_perturbation(gpu_renderer_factory, O, world):
+    """BASELINE config 5 in small: two co-registered fields merged on the GPU (value 1, value 2,
+    summed-gradient magnitude + normals; MetaVolume::mergeMV), the dense 3-D transfer function over
+    those three axes, the noise-perturbed fetch of testPert, R8k shading -- unsharded and as one of
+    eight brick shards with the halo the perturbation needs."""
+    import torch
+    from simian_spacemonkey_amd import sortlast
+    import _scenes as S
+    nx, ny, nz = 40, 36, 32
+    rng = np.random.default_rng(77)
+    z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    r2 = ((x - 20) ** 2 + (y - 18) ** 2 + (z - 16) ** 2) ** .5
+    f = np.stack([np.clip(255 - r2 * 11 + rng.normal(0, 3, x.shape), 0, 255),
+                  np.clip(np.sin(x * .35) * np.cos(y * .3) * 90 + 120 + rng.normal(0, 3, x.shape), 0, 255)], -1).astype(np.uint8)
+    R = gpu_renderer_factory()
+    try:
+        d_f = torch.from_numpy(f).cuda()
+        merged = torch.zeros((nz, ny, nx, 3), dtype=torch.uint8, device="cuda")
+        nrm = torch.zeros((nz, ny, nx, 3), dtype=torch.uint8, device="cuda")
+        R.merge_fields_device(d_f.data_ptr(), 2, (nx, ny, nz), merged.data_ptr(), nrm.data_ptr())
+        ref_m, ref_n = O.merge_addg(f)
+        assert np.array_equal(merged.cpu().numpy(), ref_m) and np.array_equal(nrm.cpu().numpy(), ref_n)
+        sc = O.Scene(ref_m, grad=ref_n)
+        sc.tf_mode, sc.tf3d = 2, S.tf3d_dense()
+        sc.xform = O.rotation((1, 1, 0), 30)
+        sc.width = sc.height = 72
+        sc.steps, sc.shade_mode = 96, 1
+        sc.noise, sc.pert_w, sc.pert_s = O.noise_tex(32), (.05, .03, 0, 0), (.2, 2.1, 4.5, 8.7)
+        rank = 5
+        if world > 1:
+            R.set_option("halo", 6)
+            R.set_shard(rank, world)
+            sc.region = sortlast.shard_region(sc.dims, rank, world)
+        # the volume goes from the merge kernel's output straight into the renderer: no host copy
+        R.upload_volume_device(merged.data_ptr(), (nx, ny, nz), 3, 0, nrm.data_ptr(), dmode="V2G")
+        S.push_scene(R, sc, upload=False)
+        R.set_option("kernel", 0)
+        img = R.render()
+        ref = sc.render()
+        assert ref[..., 3].max() > 0.05
+        assert np.abs(img - ref).max() <= 1e-4
+    finally:
+        R.close()

@@ -167,3 +167,24 @@ def test_hist2d_float_bins_stop_at_two_to_the_24(R, O):
     assert big > 2 ** 24
     want_small = int(np.float32(np.float32(np.log(float(small))) / np.float32(np.log(float(2 ** 24))) * 255))
     assert got[0, 0] == 255 and got[9, 7] == want_small and np.count_nonzero(got) == 2
+
+
+@pytest.mark.parametrize("nf,dims", [(2, (23, 17, 12)), (1, (9, 30, 7)), (3, (16, 16, 16))])
+def test_merge_fields_bit_exact(R, O, nf, dims):
+    """MetaVolume::mergeMV + addG on the GPU: interleaved fields, gradient magnitude of the summed
+    per-field differences scaled by its maximum, and the normal bytes -- every byte as the CPU
+    restatement computes it"""
+    import torch
+    nx, ny, nz = dims
+    rng = np.random.default_rng(31 + nf)
+    z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    f = np.stack([np.clip(np.sin(x * (.2 + .1 * e)) * 70 + np.cos(y * .3 + z * (.2 + .05 * e)) * 50 + 128 +
+                          rng.normal(0, 5, x.shape), 0, 255) for e in range(nf)], axis=-1).astype(np.uint8)
+    ref, refn = O.merge_addg(f)
+    out = torch.zeros((nz, ny, nx, nf + 1), dtype=torch.uint8, device="cuda")
+    nrm = torch.zeros((nz, ny, nx, 3), dtype=torch.uint8, device="cuda")
+    R.merge_fields_device(_dev(f).data_ptr(), nf, dims, out.data_ptr(), nrm.data_ptr())
+    torch.cuda.synchronize()
+    assert ref[..., nf].max() == 255
+    assert np.array_equal(out.cpu().numpy(), ref)
+    assert np.array_equal(nrm.cpu().numpy(), refn)
