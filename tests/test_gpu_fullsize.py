@@ -107,3 +107,87 @@ def test_full_size_two_shards_composite_to_whole(gpu_renderer_factory):
     finally:
         for r in rs:
             r.close()
+
+
+def test_full_size_cfg5_multi_field_perturbed(gpu_renderer_factory, O):
+    """BASELINE config 5 at its full size: two 512^3 fields merged on the GPU (mergeMV + addG),
+    dense 3-D transfer function, testPert's noise-perturbed fetch, 1024^2 x 1024 planes (gather
+    kernel).  The CPU checker agrees on 300 random rays of the frame, and the frame rendered as two
+    brick shards (halo wide enough for the perturbation) composites back to it."""
+    import torch
+    import _scenes as S
+    n, size, planes = 512, 1024, 1024
+    b = _bench()
+    rs = []
+    try:
+        r = gpu_renderer_factory()
+        rs.append(r)
+        fields = torch.empty((n, n, n, 2), dtype=torch.uint8, device="cuda")
+        one = torch.empty((n, n, n), dtype=torch.uint8, device="cuda")
+        for e, seed in enumerate((1, 2)):
+            r.synth_volume_device(0, seed, (n, n, n), one.data_ptr())
+            fields[..., e] = one if e == 0 else one.flip(2)       # the second field: another seed, mirrored
+        del one
+        merged = torch.empty((n, n, n, 3), dtype=torch.uint8, device="cuda")
+        nrm = torch.empty((n, n, n, 3), dtype=torch.uint8, device="cuda")
+        r.merge_fields_device(fields.data_ptr(), 2, (n, n, n), merged.data_ptr(), nrm.data_ptr())
+        del fields
+        xform = b.rotation((1, 1, 0), 30)
+        mv = b.modelview(xform, (1.0, 1.0, 1.0))
+        noise = O.noise_tex(32)
+        tf3d = S.tf3d_dense()
+
+        def setup(rr):
+            rr.upload_volume_device(merged.data_ptr(), (n, n, n), 3, 0, nrm.data_ptr(), dmode="V2G")
+            rr.set_option("tf_raw", 1)
+            rr.set_tf3d(tf3d)
+            rr.set_camera(mv, b.FRUSTUM, (1.0, 20.0), size, size)
+            rr.set_sampling(0.0, planes, 1.0, 1)
+            rr.set_shading("r8k", b.LIGHT, b.EYE, b.AT, [float(v) for v in xform.T.reshape(-1)], b.INTENS)
+            rr.set_perturb(noise, (.02, .01, 0, 0), (.2, 2.1, 4.5, 8.7))
+            rr.set_option("kernel", 0)
+
+        setup(r)
+        whole = torch.zeros((size * size, 4), dtype=torch.float32, device="cuda")
+        r.render_device(whole.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        assert r.last_frame_info()[0] == 1
+        import time
+        t0 = time.perf_counter()
+        for _ in range(3):
+            r.render_device(whole.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        print("cfg5 at full size, one GPU, gather kernel: %.2f ms per 1024 x 1024 x 1024-plane frame" % ((time.perf_counter() - t0) / 3 * 1e3))
+        w = whole.cpu().numpy().reshape(size, size, 4)
+        assert w[..., 3].max() > 0.5
+        sc = O.Scene(merged.cpu().numpy(), grad=nrm.cpu().numpy())
+        sc.tf_mode, sc.tf3d = 2, tf3d
+        sc.width = sc.height = size
+        sc.steps = planes
+        sc.xform = [float(v) for v in xform.T.reshape(-1)]
+        sc.mv_override = mv
+        sc.shade_mode, sc.use_spec = 1, 1
+        sc.frustum = b.FRUSTUM
+        sc.noise, sc.pert_w, sc.pert_s = noise, (.02, .01, 0, 0), (.2, 2.1, 4.5, 8.7)
+        rng = np.random.default_rng(8)
+        pix = rng.integers(0, size, size=(300, 2)).astype(np.int32)
+        ref = sc.render_pixels(pix)
+        assert ref[:, 3].max() > 0.5
+        assert np.abs(w[pix[:, 1], pix[:, 0]] - ref).max() <= 1e-4
+        del sc
+        layers = torch.zeros((2, size * size, 4), dtype=torch.float32, device="cuda")
+        for rank in (0, 1):
+            rr = gpu_renderer_factory()
+            rs.append(rr)
+            rr.set_option("halo", 16)         # .03 of 512 voxels of displacement + the texel pair
+            rr.set_shard(rank, 2)
+            setup(rr)
+            rr.render_device(layers[rank].data_ptr(), None, None)
+        torch.cuda.synchronize()
+        out = torch.zeros((size * size, 4), dtype=torch.float32, device="cuda")
+        rs[1].composite_over_device(layers.data_ptr(), 2, rs[1].shard_order(2), size * size, out.data_ptr(), None)
+        torch.cuda.synchronize()
+        assert (out - whole).abs().max().item() <= 2e-5
+    finally:
+        for r in rs:
+            r.close()
