@@ -448,10 +448,11 @@ __global__ __launch_bounds__(1024) void smk_k_hist2d(const unsigned char *vol, i
 }
 
 static int hist2d_count(smk_ctx *c, const unsigned char *d_vol, int nelts, size_t nvox, unsigned *d_bins) {
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[64] = {};  // per device
+  const int dev = c->device;
+  if (dev < 0 || dev >= 64 || !attr[dev]) {
     PCHK(c, hipFuncSetAttribute((const void *)smk_k_hist2d, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    attr = true;
+    if (dev >= 0 && dev < 64) attr[dev] = true;
   }
   const size_t nchunks = (nvox + SMK_HIST_CHUNK - 1) / SMK_HIST_CHUNK;
   const unsigned blocks = (unsigned)std::min<size_t>(nchunks, 256 * 4);

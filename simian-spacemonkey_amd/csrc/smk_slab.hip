@@ -1058,11 +1058,13 @@ bool slab_bundle_slice_range(const RenderParams &P, double fx0, double fy0, doub
 template <int DT, int SH, int PERM, int NW, int NL, bool DIAG>
 static hipError_t launch_slab(const RenderParams &P, const SlabParams &Q, size_t lds, int nblocks, hipStream_t s) {
   auto k = smk_k_slab<DT, SH, PERM, NW, NL, DIAG>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   hipLaunchKernelGGL(k, dim3(nblocks), dim3((NW + NL) * 64), lds, s, P, Q);
   return hipGetLastError();
