@@ -663,6 +663,7 @@ extern "C" int smk_set_option(smk_ctx *c, const char *key, int value) {
   if (!c || !key) return 1;
   if (!strcmp(key, "kernel")) c->opt_kernel = value;
   else if (!strcmp(key, "slab_T")) c->opt_slab_T = value;
+  else if (!strcmp(key, "slab_fly")) c->opt_slab_fly = value < 0 ? 0 : (value > 63 ? 63 : value);
   else if (!strcmp(key, "tile")) c->opt_tile = value;
   else if (!strcmp(key, "wave_w")) {
     if (!(value == 1 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == 64)) FAIL(c, "smk_set_option: wave_w must be a power of two <= 64");
@@ -983,11 +984,11 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
     const char *why = nullptr;
     const int forced = c->opt_kernel == 2;
     c->slab.frame_ev0 = c->ev0;
-    hipError_t e = smk_launch_slab(P, c->dtype, shade_kind_of(c), c->opt_slab_T, c->opt_tile, forced, c->d_vox,
+    hipError_t e = smk_launch_slab(P, c->dtype, shade_kind_of(c), c->opt_slab_T | (c->opt_slab_fly << 8), c->opt_tile, forced, c->d_vox,
                                    c->d_vox_x, &c->slab, &why, s);
     if (e == hipErrorNotSupported && why && !strcmp(why, "x-major copy unavailable")) {
       if (make_xmajor_copy(c)) return 1;
-      e = smk_launch_slab(P, c->dtype, shade_kind_of(c), c->opt_slab_T, c->opt_tile, forced, c->d_vox, c->d_vox_x,
+      e = smk_launch_slab(P, c->dtype, shade_kind_of(c), c->opt_slab_T | (c->opt_slab_fly << 8), c->opt_tile, forced, c->d_vox, c->d_vox_x,
                           &c->slab, &why, s);
     }
     if (e == hipSuccess) c->last_kernel = 2;

@@ -156,6 +156,7 @@ struct smk_ctx {
 
   // options / stats
   int opt_kernel = 0, opt_slab_T = 0, opt_tf_raw = 0, opt_tile = 0;
+  int opt_slab_fly = 0;  // slices a loader keeps in flight (0 = default)
   int opt_wave_w = 8, opt_blk_w = 2, opt_lockstep = 1;
   SlabAux slab;  // slice-ring kernel side buffers
   // auto mode (option kernel = 0) picks the ray-marcher by measurement: the first frames of a

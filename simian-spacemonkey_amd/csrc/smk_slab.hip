@@ -1074,6 +1074,8 @@ static hipError_t launch_slab(const RenderParams &P, const SlabParams &Q, size_t
 hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T, int opt_tile, int forced,
                            const void *vox_native, const void *vox_xmajor, SlabAux *aux, const char **why,
                            hipStream_t s) {
+  const int opt_fly = (opt_T >> 8) & 0xff;  // (developer knobs travel packed: slab_T | slab_fly << 8)
+  opt_T &= 0xff;
   *why = nullptr;
   if (P.pert_on) { *why = "perturbation"; return hipErrorNotSupported; }
   if (P.depth) { *why = "first-hit depth requested"; return hipErrorNotSupported; }  // (a register the fast path cannot spare)
@@ -1245,11 +1247,18 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     if (ns < 3) { if (ci + 1 < ncfg) continue; *why = "window does not fit LDS"; return hipErrorNotSupported; }
     Q.nslots = ns;
     const int mych = (Q.groups + nl - 1) / nl * Q.per;  // most DMA instructions one loader issues per slice
-    Q.maxfly = std::max(1, std::min(ns, 63 / mych + 1));
+    // Slices a loader keeps in flight.  TWO: a loader publishes a slice as landed only when it stops
+    // issuing and waits for the oldest one, so a deep issue window delays every consumer that polls
+    // for that slice -- and two slices per loader already cover the memory latency (4 loaders x 2 x
+    // ~7 KiB per CU).  Measured (frames per setting 5/4/3/2/1 on a 5-slot ring): 1024^3 f32 4.27 /
+    // 4.19 / 4.03 / 3.84 / 4.36 ms; 512^3 f32 (12 slots) 1.81 at 12, 1.66 at 2-4, 1.80 at 1; 1024^3 u8
+    // 3.54 -> 2.94 ms.
+    Q.maxfly = std::max(1, std::min(std::min(ns, 63 / mych + 1), opt_fly > 0 ? opt_fly : 2));
     // a deep ring lets the whole band step together (every lane active); on a short one a wave that
     // waits for its whole band leaves the loaders nothing to overlap with (measured, 1024^3: 5 slots,
     // wstep 0 / 1 / 2 -> 5.5 / 5.8 / 6.8 ms)
-    Q.wstep = std::max(0, std::min((int)ceil(fabs(Bc[as])), ns - 5));
+    // (re-measured with two slices in flight per loader, 5 slots: wstep 0 / 1 / 2 -> 3.80 / 3.68 / 4.68 ms)
+    Q.wstep = std::max(0, std::min((int)ceil(fabs(Bc[as])), ns - 4));
     if (opt_T > 0) Q.wstep = std::max(0, std::min(opt_T - 1, ns - 3));  // (experiment knob: slab_T = wstep + 1)
     Q.pmask = ns >= 2 * band ? 1 : 0;
     const size_t lds = (size_t)ns * Q.slot_bytes + fixed;
