@@ -553,18 +553,38 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             // there, so that a group is `per` wave-instructions: the in-order vmcnt counts slices
             // through the per-slice instruction counts kept in fly_counts).
             bool cm[7];
+            unsigned long long mk[7];  // the same column masks as wave-uniform lane masks (EXEC values)
 #pragma unroll
-            for (int k = 0; k < 7; ++k) cm[k] = k < per && colk[k] < need_u;
+            for (int k = 0; k < 7; ++k) {
+              cm[k] = k < per && colk[k] < need_u;
+              mk[k] = __builtin_amdgcn_ballot_w64(cm[k]);
+            }
             for (int g = 0; g < mygroups; ++g) {
               if (FIFO) {
                 if (row0 >= need_v) break;  // nothing of this group (or the following ones) is needed: not issued, not counted
                 issued += per;
               }
               if (row0 + (unsigned)rpg <= need_v) {
+                if (per == 3) {
+                  // a whole group in ONE statement: EXEC takes each chunk's column mask in turn, M0 steps
+                  // through the chunks' LDS images -- three scalar instructions per chunk and no branch
+                  // (every chunk has a column-0 lane, so no mask is empty)
+                  unsigned long long keep_exec;
+                  asm volatile("s_mov_b32 %[km], m0\n\ts_mov_b64 %[ke], exec\n\ts_mov_b32 m0, %[dst]\n\t"
+                               "s_mov_b64 exec, %[e0]\n\tglobal_load_lds_dwordx4 %[v0], %[src]\n\ts_add_u32 m0, m0, 0x400\n\t"
+                               "s_mov_b64 exec, %[e1]\n\tglobal_load_lds_dwordx4 %[v1], %[src]\n\ts_add_u32 m0, m0, 0x400\n\t"
+                               "s_mov_b64 exec, %[e2]\n\tglobal_load_lds_dwordx4 %[v2], %[src]\n\t"
+                               "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]"
+                               : [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)
+                               : [dst] "s"(dst), [src] "s"(src), [e0] "s"(mk[0]), [e1] "s"(mk[1]), [e2] "s"(mk[2]), [v0] "v"(voff[0]),
+                                 [v1] "v"(voff[1]), [v2] "v"(voff[2])
+                               : "memory", "scc");
+                } else {
 #define SLAB_CHUNK_ROWS_OK(k) \
   if (cm[k]) SLAB_DMA(src, dst + k * 1024u, voff[k]);
-                SLAB_GROUP(SLAB_CHUNK_ROWS_OK)
+                  SLAB_GROUP(SLAB_CHUNK_ROWS_OK)
 #undef SLAB_CHUNK_ROWS_OK
+                }
               } else {
 #define SLAB_CHUNK_MASKED(k)                                                                  \
   {                                                                                           \
@@ -700,7 +720,10 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
               }
               // (backing off further for waves whose first slice is many slices away was measured
               //  slower: reaction time matters more than the polls' issue slots)
-              __builtin_amdgcn_s_sleep(2);
+#ifndef SLAB_POLL_SLEEP
+#define SLAB_POLL_SLEEP 2
+#endif
+              __builtin_amdgcn_s_sleep(SLAB_POLL_SLEEP);
               have = landed_all();
             }
           }
@@ -1135,6 +1158,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
   else if (opt_tile == 11) { cfgs[0] = {24, 24, 2}; ncfg = 1; }
   else if (opt_tile == 12) { cfgs[0] = {48, 16, 4}; ncfg = 1; }
   else if (opt_tile == 13) { cfgs[0] = {16, 48, 4}; ncfg = 1; }
+  else if (opt_tile == 14) { cfgs[0] = {32, 24, 2}; ncfg = 1; }
   const int upv = dtype == 0 ? 2 : 1;
   for (int ci = 0; ci < ncfg; ++ci) {
     const int tw = cfgs[ci].tw, th = cfgs[ci].th, nl = cfgs[ci].nl;
