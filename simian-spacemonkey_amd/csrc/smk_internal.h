@@ -73,6 +73,8 @@ struct SlabAux {
   int order_next = 0;
   int order_cap = 0;
   std::vector<int> order_host;  // what d_order holds
+  std::vector<int> plan_work, plan_order;  // the weights the last schedule was built from, and that schedule
+  int plan_slots = 0;
   // per-tile workgroup durations of an earlier frame: the schedule's weights
   unsigned *d_ticks = nullptr, *h_ticks = nullptr;  // device buffer the kernel writes; pinned copy in flight
   int ticks_cap = 0, ticks_pending_n = 0, ticks_age = 0, ticks_adopted = 0;
