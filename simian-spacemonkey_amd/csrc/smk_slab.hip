@@ -1242,7 +1242,10 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     Q.groups = (Q.wv + Q.rpg - 1) / Q.rpg;
     Q.chunks = Q.groups * Q.per;
     Q.slot_bytes = Q.chunks * 1024;
-    Q.mask_need = Q.chunks >= 12 ? 1 : 0;
+    // per-slice extents (and with them the table-occupancy bitmap) from four chunks per slice up:
+    // re-measured with two slices in flight, 512^3 f32 1.66 -> 1.58 ms, 512^3 u8 1.72 -> 1.68,
+    // 256^3 at 1024^2 1.72 -> 1.55 (the first threshold, 12 chunks, dated from five slices in flight)
+    Q.mask_need = Q.chunks >= 4 ? 1 : 0;
     if ((Q.groups + nl - 1) / nl * Q.per > 63) { if (ci + 1 < ncfg) continue; *why = "window needs more than 63 DMA chunks per loader"; return hipErrorNotSupported; }
     // light enough for this configuration?  otherwise try the next (heavier-duty) one
     if (ci + 1 < ncfg && (double)Q.chunks * 1024.0 / (nw * 64) > 16.0 * nl) continue;
