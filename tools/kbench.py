@@ -40,7 +40,15 @@ def main():
     del vghf, nrm
     torch.cuda.empty_cache()
     bench.configure(r, a.workload, n, a.size, a.planes)
-    if a.pose != "rot":
+    if a.pose.startswith("close"):
+        # a close-up: strong perspective, rays far from the principal axis at the frame's edges
+        dist = float(a.pose[5:] or 2.0)
+        xform = bench.rotation((1, 1, 0), 30)
+        M = bench.look_at((0.1, -0.05, -dist), bench.AT, bench.UP) @ xform @ bench.translate([-0.5, -0.5, -0.5])
+        w = 0.42
+        r.set_camera([float(v) for v in M.T.reshape(-1)], (-w, w, -w, w), (1.0, 20.0), a.size, a.size)
+        r.set_shading("r8k", bench.LIGHT, (0.1, -0.05, -dist), bench.AT, [float(v) for v in xform.T.reshape(-1)], bench.INTENS)
+    elif a.pose != "rot":
         ax, deg = {"id": ((0, 1, 0), 0), "x": ((0, 1, 0), 90), "y": ((1, 0, 0), 90), "back": ((0, 1, 0), 160),
                    "side": ((.2, 1, .1), 75), "r45": ((1, 1, 1), 45)}[a.pose]
         xform = bench.rotation(ax, deg)
