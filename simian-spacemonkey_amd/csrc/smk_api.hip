@@ -663,6 +663,7 @@ extern "C" int smk_set_option(smk_ctx *c, const char *key, int value) {
   if (!c || !key) return 1;
   if (!strcmp(key, "kernel")) c->opt_kernel = value;
   else if (!strcmp(key, "slab_T")) c->opt_slab_T = value;
+  else if (!strcmp(key, "inject_slab_status")) c->opt_inject_status = value;
   else if (!strcmp(key, "slab_fly")) c->opt_slab_fly = value < 0 ? 0 : (value > 63 ? 63 : value);
   else if (!strcmp(key, "tile")) c->opt_tile = value;
   else if (!strcmp(key, "wave_w")) {
@@ -716,6 +717,8 @@ static int check_slab_status(smk_ctx *c) {
   int st = *(volatile int *)c->slab.h_status;
   if (!st) return 0;
   *(volatile int *)c->slab.h_status = 0;
+  // never twice: in auto mode that configuration is the gather kernel's from now on
+  if (c->opt_kernel == 0 && c->last_slab_sig) c->tune_choice[c->last_slab_sig] = 1;
   FAIL(c, "slice-ring kernel reported %s (status %d); frame invalid", st == 1 ? "a producer/consumer time-out" : "a window outside its host bound", st);
 }
 
@@ -934,6 +937,7 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
   // no perturbation, rays sharing one principal axis), the generic gather kernel otherwise
   c->last_kernel = 1;
   c->slab_why.clear();
+  if (check_slab_status(c)) return 1;  // an earlier asynchronous frame failed (and its configuration now belongs to the gather kernel)
   // ---- auto mode: which kernel for this configuration?
   bool try_slab = c->opt_kernel != 1 && c->tf_mode == 1;
   unsigned long long sig = 0;
@@ -979,7 +983,6 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
       *c->slab.h_status = 0;
       HIPCHK(c, hipMalloc((void **)&c->slab.d_diag, 16 * sizeof(float)));
     }
-    if (check_slab_status(c)) return 1;  // an earlier asynchronous frame failed
     if (c->opt_lockstep & 16) HIPCHK(c, hipMemsetAsync(c->slab.d_diag, 0, 16 * sizeof(float), s));
     const char *why = nullptr;
     const int forced = c->opt_kernel == 2;
@@ -991,7 +994,14 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
       e = smk_launch_slab(P, c->dtype, shade_kind_of(c), c->opt_slab_T | (c->opt_slab_fly << 8), c->opt_tile, forced, c->d_vox, c->d_vox_x,
                           &c->slab, &why, s);
     }
-    if (e == hipSuccess) c->last_kernel = 2;
+    if (e == hipSuccess) {
+      c->last_kernel = 2;
+      c->last_slab_sig = sig;
+      if (c->opt_inject_status && c->slab.h_status) {  // (test hook: what a failed frame leaves behind)
+        *(volatile int *)c->slab.h_status = c->opt_inject_status;
+        c->opt_inject_status = 0;
+      }
+    }
     else if (e == hipErrorNotSupported) {
       c->slab_why = why ? why : "?";
       if (c->opt_kernel == 2) FAIL(c, "smk_render: slab kernel forced but not applicable: %s", c->slab_why.c_str());
@@ -1035,7 +1045,19 @@ extern "C" int smk_render(smk_ctx *c, float *rgba, float *depth) {
   if (smk_render_device(c, c->d_out, depth ? c->d_depth : nullptr, c->stream)) return 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
-  if (check_slab_status(c)) return 1;
+  if (check_slab_status(c)) {
+    // the synchronous entry still owes its caller this frame: in auto mode it is rendered again, by
+    // the gather kernel (check_slab_status has just retired the slice-ring kernel for this configuration)
+    if (c->opt_kernel != 0) return 1;
+    const std::string first = c->err;
+    if (smk_render_device(c, c->d_out, depth ? c->d_depth : nullptr, c->stream)) return 1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->last_kernel != 1 || check_slab_status(c)) {
+      c->err = first;
+      return 1;
+    }
+    fprintf(stderr, "[smk] %s -- frame rendered again by the gather kernel\n", first.c_str());
+  }
   HIPCHK(c, hipMemcpy(rgba, c->d_out, npix * 16, hipMemcpyDeviceToHost));
   if (depth) HIPCHK(c, hipMemcpy(depth, c->d_depth, npix * 4, hipMemcpyDeviceToHost));
   return 0;

@@ -159,12 +159,14 @@ struct smk_ctx {
   // options / stats
   int opt_kernel = 0, opt_slab_T = 0, opt_tf_raw = 0, opt_tile = 0;
   int opt_slab_fly = 0;  // slices a loader keeps in flight (0 = default)
+  int opt_inject_status = 0;  // (test hook) the next slice-ring frame reports this status word
   int opt_wave_w = 8, opt_blk_w = 2, opt_lockstep = 1;
   SlabAux slab;  // slice-ring kernel side buffers
   // auto mode (option kernel = 0) picks the ray-marcher by measurement: the first frames of a
   // new configuration run the slice-ring kernel, then the gather kernel (bit-identical frames),
   // and the faster one is kept for that configuration
   std::map<unsigned long long, int> tune_choice;
+  unsigned long long last_slab_sig = 0;  // configuration of the latest slice-ring launch (a failed one is not tried again)
   unsigned long long tune_sig = 0;
   int tune_state = 0, tune_slot[2] = {0, 0};
   int last_kernel = 0;

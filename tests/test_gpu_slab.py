@@ -278,3 +278,47 @@ def test_free_clip_plane_runs_on_the_gather_kernel(R, pose):
     sc.clip_plane = None
     a, b = _both(R, sc, upload=False)
     assert np.array_equal(a, b) and np.abs(b - whole).max() <= TOL
+
+
+def test_a_failed_slice_ring_frame_is_rendered_again_and_not_tried_twice(gpu_renderer_factory):
+    """Safety net: should the slice-ring kernel ever report a time-out or a violated window bound,
+    the synchronous entry re-renders that frame on the gather kernel in auto mode (the caller gets
+    a valid frame), the configuration stays with the gather kernel, and a forced slice-ring frame
+    reports the failure.  The status word is injected through a test hook."""
+    import torch
+    r = gpu_renderer_factory()
+    try:
+        sc = make_scene("cfg3", n=32, size=64, steps=64, pose="rot", f32=True, shade=1)
+        ref = sc.render()
+        push_scene(r, sc)
+        r.set_option("kernel", 0)
+        for _ in range(5):                                   # trials done, slice-ring kernel chosen
+            img = r.render()
+        assert r.last_frame_info()[0] == 2
+        r.set_option("inject_slab_status", 2)
+        img = r.render()                                     # fails behind the scenes, rendered again
+        assert r.last_frame_info()[0] == 1 and np.abs(img - ref).max() <= TOL
+        assert r.stat("slab_status") == 0
+        img = r.render()
+        assert r.last_frame_info()[0] == 1 and np.abs(img - ref).max() <= TOL   # not tried twice
+        r.set_option("kernel", 2)
+        r.set_option("inject_slab_status", 1)
+        with pytest.raises(Exception, match="time-out"):
+            r.render()
+        assert np.abs(r.render() - ref).max() <= TOL         # the next forced frame is fine
+        # asynchronous entry: the failure surfaces at the next call, after which auto mode uses the gather kernel
+        sc.steps = 65                                        # a new configuration
+        push_scene(r, sc, upload=False)
+        r.set_option("kernel", 0)
+        out = torch.zeros((64 * 64, 4), dtype=torch.float32, device="cuda")
+        r.set_option("inject_slab_status", 2)
+        r.render_device(out.data_ptr(), None, None)          # first trial frame = slice-ring kernel
+        torch.cuda.synchronize()
+        with pytest.raises(Exception, match="window outside"):
+            r.render_device(out.data_ptr(), None, None)
+        r.render_device(out.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        assert r.last_frame_info()[0] == 1
+        assert np.abs(out.cpu().numpy().reshape(64, 64, 4) - sc.render()).max() <= TOL
+    finally:
+        r.close()
