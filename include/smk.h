@@ -175,9 +175,10 @@ int smk_get_raycoef(smk_ctx *ctx, smk_raycoef *out);
  *              mode); 2 slice-ring kernel (fails where it does not apply, with the reason)
  *   "tf_raw"   [0] 1: the 2-D table handed to smk_set_tf2d is already opacity-corrected (copyScale off)
  *   "halo"     [1] voxels of halo kept around a shard's region (before smk_upload_volume)
- *   developer knobs: "tile" (slice-ring workgroup shape id), "slab_T, slab_fly" (band wait + 1), "lockstep"
- *   (bit 0 gather lockstep; bits 1..6 slice-ring diagnostics, see tools/kbench.py),
- *   "wave_w"/"blk_w" (gather tile shape) */
+ *   developer knobs: "tile" (slice-ring workgroup shape id), "slab_T" (band wait + 1), "slab_fly"
+ *   (slices a loader keeps in flight), "lockstep" (bit 0 gather lockstep; bits 1..6 slice-ring
+ *   diagnostics, see tools/kbench.py), "wave_w"/"blk_w" (gather tile shape), "inject_slab_status"
+ *   (test hook: the next slice-ring frame reports this status word) */
 int smk_set_option(smk_ctx *ctx, const char *key, int value);
 /* last frame: which kernel ran (1/2), its HIP-event time in ms, algorithmic bytes */
 int smk_last_frame_info(smk_ctx *ctx, int *kernel, float *ms, double *alg_bytes);
