@@ -426,9 +426,9 @@ def copy_scale(tex, sr):
 def lev_widget(kind, b=(.5, 0), l=(.3, .7), r=(.7, .7), tw=-10, th=-10, hsl=(0, 1, .5),
                alpha=.5, be=1.0, faux=False):
     """LevWidget with the constructor defaults (LevWidget.cpp:35-63) and TFWidgetRen::init's
-    position (TFWidgetRen1.cpp:631-633); kind = 'triangle' | 'ellipse'"""
+    position (TFWidgetRen1.cpp:631-633); kind = 'triangle' | 'ellipse' | '1d' | 'default'"""
     w = LevWidget()
-    w.type = 0 if kind == "triangle" else 1
+    w.type = {"triangle": 0, "ellipse": 1, "1d": 2, "default": 3}[kind]
     lib().orc_lev_setpos(C.byref(w), _f3(b), _f3(l), _f3(r), tw, th)
     col = (C.c_float * 3)()
     lib().orc_hsl_color(*hsl, col)

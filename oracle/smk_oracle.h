@@ -178,7 +178,8 @@ void orc_tlut_premultiply(const float *rgba, int size, float *table);           
 void orc_deptex_default(unsigned char *deptex, unsigned char *deptex2, int sx, int sy);
 void orc_copy_scale(const unsigned char *in, unsigned char *out, int sx, int sy, float sr);
 
-/* LevWidget::rasterize (LevWidget.cpp:674-1074), types: 0 triangle, 1 ellipse("square") */
+/* LevWidget::rasterize (LevWidget.cpp:674-1074), types as LevWidget.h:117-120: 0 triangle,
+ * 1 ellipse ("square"), 2 1-D style, 3 default style */
 typedef struct {
   int type;
   float verts[3][2];  /* bottom, left, right (setPos, :1098-1125) */

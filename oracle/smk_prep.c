@@ -688,14 +688,18 @@ void orc_lev_setpos(orc_levwidget *w, const float b[2], const float l[2], const 
 }
 
 /* colour blend + alpha write shared by every shape (e.g. LevWidget.cpp:737-759, 788-806) */
-static inline void lev_pixel(const orc_levwidget *w, unsigned char *tex, size_t offset, float tmpa,
-                             float cs, float alphaScale, int max_rule) {
-  float cw = w->faux ? tmpa * cs : tmpa;
+static inline void lev_pixel_col(const orc_levwidget *w, const float *color, int use_faux, unsigned char *tex, size_t offset,
+                                 float tmpa, float cs, float alphaScale, int max_rule) {
+  float cw = (use_faux && w->faux) ? tmpa * cs : tmpa;
   float tmpta = tex[offset + 3] / 255.0f;
   for (int e = 0; e < 3; ++e)
-    tex[offset + e] = uc_cast((tmpta * tex[offset + e] / 255.0 + cw * w->color[e]) / (tmpta + tmpa) * 255);
+    tex[offset + e] = uc_cast((tmpta * tex[offset + e] / 255.0 + cw * color[e]) / (tmpta + tmpa) * 255);
   if (max_rule) tex[offset + 3] = uc_cast(MAXF(tmpa * 255, tex[offset + 3]) * alphaScale);
   else tex[offset + 3] = uc_cast((tmpa * 255 + (1.0 - tmpa) * tex[offset + 3]) * alphaScale);
+}
+static inline void lev_pixel(const orc_levwidget *w, unsigned char *tex, size_t offset, float tmpa,
+                             float cs, float alphaScale, int max_rule) {
+  lev_pixel_col(w, w->color, 1, tex, offset, tmpa, cs, alphaScale, max_rule);
 }
 
 void orc_lev_rasterize(const orc_levwidget *w, unsigned char *tex, int sv, int sg, int sh) {
@@ -718,6 +722,61 @@ void orc_lev_rasterize(const orc_levwidget *w, unsigned char *tex, int sv, int s
           float cs = tmpa;
           tmpa *= w->alpha;
           lev_pixel(w, tex, offset, tmpa, cs, alphaScale, 1);
+        }
+      }
+    }
+  } else if (w->type == 2) {
+    /* 1-D style (:903-1019): a plateau of full alpha with linear ramps either side, every scan
+     * line of the widget's height the same; no boundary-emphasis scale on this shape */
+    int hc = (int)((w->thresh[0] - verts[1][0]) * sv);
+    float vthresh = (w->thresh[1] - verts[0][1]) / (verts[1][1] - verts[0][1]);
+    for (int k = 0; k < sh; ++k)
+      for (int i = (int)(verts[0][1] * sg); i < H + 1; ++i) {
+        int start = (int)(verts[1][0] * sv);
+        int dist = (int)(verts[2][0] * sv - start);
+        int hc0 = (int)(hc * (1.0 - vthresh) + 1);
+        int hc1 = (int)(dist - (dist - hc) * (1.0 - vthresh) + 1);
+        int j = 0;
+        for (; j < hc0; ++j) {
+          float tmpa = (float)affine(0, j, hc0, 0, 1);
+          float cs = tmpa;
+          tmpa *= w->alpha;
+          lev_pixel(w, tex, (size_t)k * sth + (size_t)i * stg + (size_t)(start + j) * stv, tmpa, cs, 1.0f, 0);
+        }
+        for (j = hc0; j < hc1; ++j) {
+          float tmpa = 1, cs = 1;
+          tmpa *= w->alpha;
+          lev_pixel(w, tex, (size_t)k * sth + (size_t)i * stg + (size_t)(start + j) * stv, tmpa, cs, 1.0f, 0);
+        }
+        for (j = hc1; j < dist; ++j) {
+          float tmpa = (float)affine(hc1, j, dist, 1, 0);
+          float cs = tmpa;
+          tmpa *= w->alpha;
+          lev_pixel(w, tex, (size_t)k * sth + (size_t)i * stg + (size_t)(start + j) * stv, tmpa, cs, 1.0f, 0);
+        }
+      }
+  } else if (w->type == 3) {
+    /* default style (:1022-1072): alpha rises along g as x/(m+x) (note the literal 255.0 where the
+     * other shapes use sg), colour walks once around the hue circle across the widget's width
+     * (HSLPicker::reset(0,1,.5) then updateHL(dc,0) per pixel, HSLPicker.cpp:44-48) */
+    float m = (w->thresh[1] - verts[0][1]) / (verts[1][1] - verts[0][1]);
+    for (int k = 0; k < sh; ++k) {
+      float alphaScale = (k != 1) ? w->be : 1;
+      int start = (int)(verts[1][0] * sv);
+      int fin = (int)(verts[2][0] * sv);
+      fin -= start;
+      float dc = 1 / ((verts[1][0] - verts[2][0]) * sv - 1);
+      for (int i = (int)(verts[0][1] * sg); i < H + 1; ++i) {
+        float tmpa = (float)(((i / 255.0) - verts[0][1]) / (m + (i / 255.0) - verts[0][1]));
+        tmpa *= w->alpha;
+        tmpa = tmpa > 1 ? 1 : (tmpa < 0 ? 0 : tmpa);
+        float hue = 0, lev = .5f;
+        for (int j = 0; j < fin; ++j) {
+          float cl[3];
+          hue = (float)((hue + dc) > 1.0 ? (hue + dc - 1.0) : ((hue + dc) < 0 ? (hue + dc + 1.0) : (hue + dc)));
+          lev = (lev + 0) > 1 ? 1 : (lev + 0) < 0 ? 0 : (lev + 0);
+          orc_hsl_color(hue, 1, lev, cl);
+          lev_pixel_col(w, cl, 0, tex, (size_t)k * sth + (size_t)i * stg + (size_t)(start + j) * stv, tmpa, tmpa, alphaScale, 0);
         }
       }
     }
