@@ -88,4 +88,5 @@ def test_third_axis_ramp(tmp_path, O, slider):
     got = np.fromfile(out, np.uint8).reshape(4, 256, 4)
     ref = O.rasterize_vgh(np.zeros((4, 256, 4), np.uint8), slider)
     assert np.array_equal(got, ref)
-    assert got[0, 85, 3] == 255 or slider < 1.0                    # the ramp peaks at the zero crossing
+    assert got[0, 85, 3] == 0 and got[0, 171:, 3].max() == 0       # column 85 itself and the top third are never written
+    assert got[0, 84, 3] >= got[0, 0, 3] and got[0, 86, 3] >= got[0, 170, 3]   # rises towards the zero crossing, falls after it
