@@ -47,7 +47,9 @@ def main():
     base = None
     for var in [""] + sys.argv[1:]:
         for kv in var.split(","):
-            if kv:
+            if kv == "nopert":                # (how much of the frame is the perturbation?)
+                r.set_perturb(None, None, None)
+            elif kv:
                 k, v = kv.split("=")
                 r.set_option(k, int(v))
         r.render_device(out.data_ptr(), None, None)
