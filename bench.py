@@ -200,15 +200,21 @@ def cpu_baseline(vghf, nrm, tf_path, size, planes, xform, mv, gpu_frame, budget_
     t0 = time.perf_counter()
     img = sc.render(rows=(a, b))
     dt = time.perf_counter() - t0
+    passes = 1
+    while dt < 0.8 * budget_s and passes < 8:      # a many-core host finishes the band early: repeat it
+        sc.render(rows=(a, b))
+        passes += 1
+        dt = time.perf_counter() - t0
     err = float(np.abs(img[a:b] - gpu_frame[a:b]).max())
     import ctypes
     try:
         threads = ctypes.CDLL("libgomp.so.1").omp_get_max_threads()
     except OSError:
         threads = os.cpu_count()
-    return {"value": rows * size * planes / dt / 1e6, "unit": "Msamples/s", "cores": int(threads),
+    return {"value": passes * rows * size * planes / dt / 1e6, "unit": "Msamples/s", "cores": int(threads),
             "kind": "port",
-            "sample": "rows %d..%d of the same %dx%dx%d frame (%.1f s of CPU work)" % (a, b, size, size, planes, dt),
+            "sample": "rows %d..%d of the same %dx%dx%d frame, %d pass%s (%.1f s of CPU work)"
+                      % (a, b, size, size, planes, passes, "" if passes == 1 else "es", dt),
             "host_cpus": os.cpu_count(), "parity_max_abs_err_vs_gpu": err}
 
 
