@@ -41,6 +41,13 @@ typedef enum {
   SMK_SHADE_NV20_DSPEC = 4 /* NV20VolRen3D diffuse + specular^16                                */
 } smk_shade;
 
+/* framebuffer blend of the slice polygons (SURVEY 2.1 "Framebuffer blend") */
+typedef enum {
+  SMK_BLEND_FRONT_TO_BACK = 0, /* GL_ONE_MINUS_DST_ALPHA, GL_ONE (R8kVolRen3D.cpp:1441-1449); exact early termination */
+  SMK_BLEND_BACK_TO_FRONT = 1, /* GL_ONE, GL_ONE_MINUS_SRC_ALPHA, far plane first (VolumeRenderer.cpp:590, NV20VolRen3D.cpp:930) */
+  SMK_BLEND_MAX = 2            /* glBlendEquationEXT(GL_MAX): gluvvShadeMIP (NV20VolRen3D.cpp:158-163) */
+} smk_blend;
+
 /* Exactly the fields of `class Volume` a renderer reads (MetaVolume.h:18-61): one brick as
  * produced by MetaVolume::brick (MetaVolume.cpp:1369-1452). */
 typedef struct {
@@ -119,6 +126,11 @@ int smk_set_clip(smk_ctx *ctx, int on, int oaxis, const float vpos[3]);
 int smk_set_clip_plane(smk_ctx *ctx, int on, const double plane_eye[4]);
 int smk_set_perturb(smk_ctx *ctx, const unsigned char *noise_rgba, int n, const float w[4],
                     const float s[4]);
+/* replaces the glBlendFunc / glBlendEquationEXT state of the slice loop (VolumeRenderer.cpp:589-590,
+ * NV20VolRen3D.cpp:158-163, 930; R8kVolRen3D.cpp:1436-1449).  Default: front to back.  The two
+ * "over" orders are the same operator evaluated from opposite ends (equal up to fp32 rounding);
+ * back-to-front frames run on the gather kernel. */
+int smk_set_blend(smk_ctx *ctx, smk_blend mode);
 
 /* replaces gluvvPrimitive::draw() -> renderVolume (VolumeRenderer.cpp:280-328,
  * NV20VolRen3D.cpp:87-185): one frame.  rgba_out: [height][width][4] float, premultiplied,

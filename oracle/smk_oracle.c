@@ -456,7 +456,7 @@ static long long march_pixel(const orc_volume *v, const orc_classify *tf, const 
   long long inside = 0;
   int S = rc->nplanes;
   for (int mm = 0; mm < S; ++mm) {
-    int m = blend == 0 ? mm : S - 1 - mm;
+    int m = blend == 1 ? S - 1 - mm : mm;
     float p[3];
     int in = 1;
     for (int a = 0; a < 3; ++a) {
@@ -476,6 +476,11 @@ static long long march_pixel(const orc_volume *v, const orc_classify *tf, const 
       C[1] = fmaf(w, src[1], C[1]);
       C[2] = fmaf(w, src[2], C[2]);
       C[3] = fmaf(w, src[3], C[3]);
+    } else if (blend == 2) {
+      /* D = max(S, D) per component: glBlendEquationEXT(GL_MAX), gluvvShadeMIP (NV20VolRen3D.cpp:158-163);
+       * GL_MAX ignores the blend factors */
+      if (first == INFINITY) first = fmaf((float)m, rc->dtau, rc->tau0) * znear;
+      for (int k = 0; k < 4; ++k) C[k] = src[k] > C[k] ? src[k] : C[k];
     } else {
       /* D = S + (1-S.a)*D (GL_ONE, GL_ONE_MINUS_SRC_ALPHA), far plane first */
       float w = 1.0f - src[3];

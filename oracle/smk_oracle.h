@@ -97,7 +97,8 @@ typedef struct {
 
 int orc_ray_setup(const orc_volume *v, const orc_camera *c, orc_raycoef *out);
 
-/* blend: 0 = front-to-back (R8kVolRen3D.cpp:1441-1449), 1 = back-to-front
+/* blend: 2 = maximum per component (GL_MAX, gluvvShadeMIP, NV20VolRen3D.cpp:158-163),
+ * 0 = front-to-back (R8kVolRen3D.cpp:1441-1449), 1 = back-to-front
  * (VolumeRenderer.cpp:589-590).  rgba: [height][width][4] premultiplied; depth may be NULL.
  * Rows [row0,row1) only (others untouched).  Returns 0 ok. */
 int orc_render(const orc_volume *v, const orc_classify *tf, const orc_camera *cam,

@@ -18,7 +18,7 @@ ABI_SYMBOLS = [
     "smk_create", "smk_destroy", "smk_last_error", "smk_upload_volume",
     "smk_upload_volume_device", "smk_set_shard", "smk_set_clip", "smk_set_clip_plane", "smk_hist2d", "smk_hist2d_device", "smk_merge_fields_device", "smk_shard_order", "smk_set_tlut1d",
     "smk_set_tf2d", "smk_set_tf3d", "smk_set_camera", "smk_set_shading", "smk_set_sampling",
-    "smk_set_perturb", "smk_render", "smk_render_device", "smk_composite_over_device",
+    "smk_set_perturb", "smk_set_blend", "smk_render", "smk_render_device", "smk_composite_over_device",
     "smk_make_vgh_device", "smk_normals_vgh_device", "smk_synth_volume_device",
     "smk_get_raycoef", "smk_set_option", "smk_last_frame_info", "smk_get_stat", "smk_get_trace", "smk_get_tf2d_effective",
     "smk_timing_reset", "smk_timing_read",
@@ -98,6 +98,7 @@ def load_library():
                                   P(C.c_float), C.c_float, C.c_float]
     L.smk_set_sampling.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_int]
     L.smk_set_perturb.argtypes = [C.c_void_p, C.c_void_p, C.c_int, P(C.c_float), P(C.c_float)]
+    L.smk_set_blend.argtypes = [C.c_void_p, C.c_int]
     L.smk_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.smk_render_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.smk_composite_over_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, P(C.c_int), C.c_int,
@@ -273,6 +274,11 @@ class Renderer:
             return
         noise = np.ascontiguousarray(noise, np.uint8)
         self._ck(self.L.smk_set_perturb(self.ctx, _ptr(noise), noise.shape[0], _fa(w, 4), _fa(s, 4)))
+
+    def set_blend(self, mode):
+        """0 / "ftb" front to back (default), 1 / "btf" back to front, 2 / "max" GL_MAX (MIP)"""
+        mode = {"ftb": 0, "btf": 1, "max": 2}.get(mode, mode)
+        self._ck(self.L.smk_set_blend(self.ctx, int(mode)))
 
     def set_option(self, key, value):
         self._ck(self.L.smk_set_option(self.ctx, key.encode(), int(value)))

@@ -427,6 +427,13 @@ extern "C" int smk_set_sampling(smk_ctx *c, float rate, int steps, float gamma, 
   return 0;
 }
 
+extern "C" int smk_set_blend(smk_ctx *c, smk_blend mode) {
+  if (!c) return 1;
+  if (mode < SMK_BLEND_FRONT_TO_BACK || mode > SMK_BLEND_MAX) FAIL(c, "smk_set_blend: bad mode");
+  c->blend = mode;
+  return 0;
+}
+
 extern "C" int smk_set_perturb(smk_ctx *c, const unsigned char *noise, int n, const float w[4], const float s[4]) {
   if (!c) return 1;
   HIPCHK(c, hipSetDevice(c->device));
@@ -837,6 +844,7 @@ static int build_params(smk_ctx *c, RenderParams &P) {
   P.H = c->H;
   P.znear = c->clip[0];
   shading_vectors(c, P);
+  P.blend = c->blend;
   P.noise = c->d_noise;
   P.nn = c->nn;
   P.pw[0] = c->pw[0];
@@ -1069,12 +1077,16 @@ struct OrderArg {
   int o[SMK_MAX_RANKS];
 };
 
-__global__ void smk_k_over(const float4 *layers, int nlayers, OrderArg ord, int npix, float4 *out) {
+__global__ void smk_k_over(const float4 *layers, int nlayers, OrderArg ord, int npix, float4 *out, int use_max) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= npix) return;
   float4 C = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int l = 0; l < nlayers; ++l) {
     float4 s = layers[(size_t)ord.o[l] * npix + p];
+    if (use_max) {  // GL_MAX layers merge by maximum, in any order
+      C = make_float4(fmaxf(C.x, s.x), fmaxf(C.y, s.y), fmaxf(C.z, s.z), fmaxf(C.w, s.w));
+      continue;
+    }
     float w = 1.0f - C.w;
     C.x = __fmaf_rn(w, s.x, C.x);
     C.y = __fmaf_rn(w, s.y, C.y);
@@ -1097,7 +1109,7 @@ extern "C" int smk_composite_over_device(smk_ctx *c, const void *d_layers, int n
   }
   hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   hipLaunchKernelGGL(smk_k_over, dim3((npix + 255) / 256), dim3(256), 0, s, (const float4 *)d_layers, nlayers, oa,
-                     npix, (float4 *)d_out);
+                     npix, (float4 *)d_out, c->blend == SMK_BLEND_MAX ? 1 : 0);
   HIPCHK(c, hipGetLastError());
   return 0;
 }

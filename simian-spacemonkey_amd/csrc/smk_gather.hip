@@ -66,8 +66,12 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
   float first = __int_as_float(0x7f800000);
   const int Dx = P.D[0], Dy = P.D[1];
 
-  for (int m = mlo; m <= mhi; ++m) {
-    if (!__any(m <= m1)) break;  // every ray of the wave is past its last plane (or saturated)
+  // blend order: front to back (and GL_MAX, which has no order) walk m upwards; back to front
+  // (VolumeRenderer.cpp:590) starts at the far plane
+  const bool btf = P.blend == SMK_BLEND_BACK_TO_FRONT;
+  for (int t = 0, nt = mhi - mlo + 1; t < nt; ++t) {
+    const int m = btf ? mhi - t : mlo + t;
+    if (!btf && !__any(m <= m1)) break;  // every ray of the wave is past its last plane (or saturated)
     if (m < m0 || m > m1) continue;
     float p0 = __fmaf_rn((float)m, B[0], A[0]);
     float p1 = __fmaf_rn((float)m, B[1], A[1]);
@@ -148,16 +152,33 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
       float n2 = smk_nrm(k000.nb, k100.nb, k010.nb, k110.nb, k001.nb, k101.nb, k011.nb, k111.nb, 2, fx, fy, fz);
       src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1);
     }
-    // C += (1-A) src   (GL_ONE_MINUS_DST_ALPHA, GL_ONE)
-    float w = 1.0f - C3;
-    if (first == __int_as_float(0x7f800000)) first = __fmaf_rn((float)m, rc.dtau, rc.tau0) * P.znear;
-    C0 = __fmaf_rn(w, src.x, C0);
-    C1 = __fmaf_rn(w, src.y, C1);
-    C2 = __fmaf_rn(w, src.z, C2);
-    C3 = __fmaf_rn(w, src.w, C3);
-    // exact early termination: once A == 1.0f every later weight (1-A) is exactly 0, so no
-    // later sample can change C or A (nor the first-hit depth)
-    if (C3 == 1.0f) m1 = m;
+    if (P.blend == SMK_BLEND_FRONT_TO_BACK) {
+      // C += (1-A) src   (GL_ONE_MINUS_DST_ALPHA, GL_ONE)
+      float w = 1.0f - C3;
+      if (first == __int_as_float(0x7f800000)) first = __fmaf_rn((float)m, rc.dtau, rc.tau0) * P.znear;
+      C0 = __fmaf_rn(w, src.x, C0);
+      C1 = __fmaf_rn(w, src.y, C1);
+      C2 = __fmaf_rn(w, src.z, C2);
+      C3 = __fmaf_rn(w, src.w, C3);
+      // exact early termination: once A == 1.0f every later weight (1-A) is exactly 0, so no
+      // later sample can change C or A (nor the first-hit depth)
+      if (C3 == 1.0f) m1 = m;
+    } else if (btf) {
+      // D = S + (1-S.a) D   (GL_ONE, GL_ONE_MINUS_SRC_ALPHA); the nearest contributing sample is the last one
+      float w = 1.0f - src.w;
+      first = __fmaf_rn((float)m, rc.dtau, rc.tau0) * P.znear;
+      C0 = __fmaf_rn(w, C0, src.x);
+      C1 = __fmaf_rn(w, C1, src.y);
+      C2 = __fmaf_rn(w, C2, src.z);
+      C3 = __fmaf_rn(w, C3, src.w);
+    } else {
+      // D = max(S, D) per component (GL_MAX ignores the blend factors)
+      if (first == __int_as_float(0x7f800000)) first = __fmaf_rn((float)m, rc.dtau, rc.tau0) * P.znear;
+      C0 = fmaxf(C0, src.x);
+      C1 = fmaxf(C1, src.y);
+      C2 = fmaxf(C2, src.z);
+      C3 = fmaxf(C3, src.w);
+    }
   }
   if (!live) return;
   size_t o = (size_t)j * P.W + i;

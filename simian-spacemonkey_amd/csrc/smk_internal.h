@@ -50,6 +50,7 @@ struct RenderParams {
   float L[3], Hv[3];
   float R[9];  // rows of rinfo.xform's rotation: Nw = R * n
   float intens;
+  int blend;  // smk_blend
   // ---- perturbation
   const uint32_t *noise;  // [nn][nn][nn] RGBA8
   int nn, pert_on;
@@ -141,6 +142,7 @@ struct smk_ctx {
   int steps = 0, scale_alphas = 1;
 
   // shading
+  int blend = 0;  // smk_blend
   int shade = 0;
   float light_pos[3] = {0, 0, -5}, eye[3] = {0, 0, -7}, at[3] = {0, 0, 0};
   float xform[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};

@@ -72,6 +72,10 @@ struct SlabParams {
 };
 
 #define SLAB_EPS 0.02f
+// cache policy of the LDS-DMA stream ("" = default, " nt" = non-temporal); an experiment knob
+#ifndef SLAB_DMA_POLICY
+#define SLAB_DMA_POLICY ""
+#endif
 #define SLAB_DONE 0x3fffffff
 
 template <int DT>
@@ -495,7 +499,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       // (saddr form: no per-chunk VALU; M0 written in the statement that reads it)
       unsigned keep_m0;
 #define SLAB_DMA(src_, dst_, voff_)                                                                                 \
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0" \
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3" SLAB_DMA_POLICY "\n\ts_mov_b32 m0, %0" \
                : "=&s"(keep_m0)                                                                                     \
                : "v"(voff_), "s"(dst_), "s"(src_)                                                                   \
                : "memory")
@@ -572,9 +576,9 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
                   // (every chunk has a column-0 lane, so no mask is empty)
                   unsigned long long keep_exec;
                   asm volatile("s_mov_b32 %[km], m0\n\ts_mov_b64 %[ke], exec\n\ts_mov_b32 m0, %[dst]\n\t"
-                               "s_mov_b64 exec, %[e0]\n\tglobal_load_lds_dwordx4 %[v0], %[src]\n\ts_add_u32 m0, m0, 0x400\n\t"
-                               "s_mov_b64 exec, %[e1]\n\tglobal_load_lds_dwordx4 %[v1], %[src]\n\ts_add_u32 m0, m0, 0x400\n\t"
-                               "s_mov_b64 exec, %[e2]\n\tglobal_load_lds_dwordx4 %[v2], %[src]\n\t"
+                               "s_mov_b64 exec, %[e0]\n\tglobal_load_lds_dwordx4 %[v0], %[src]" SLAB_DMA_POLICY "\n\ts_add_u32 m0, m0, 0x400\n\t"
+                               "s_mov_b64 exec, %[e1]\n\tglobal_load_lds_dwordx4 %[v1], %[src]" SLAB_DMA_POLICY "\n\ts_add_u32 m0, m0, 0x400\n\t"
+                               "s_mov_b64 exec, %[e2]\n\tglobal_load_lds_dwordx4 %[v2], %[src]" SLAB_DMA_POLICY "\n\t"
                                "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]"
                                : [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)
                                : [dst] "s"(dst), [src] "s"(src), [e0] "s"(mk[0]), [e1] "s"(mk[1]), [e2] "s"(mk[2]), [v0] "v"(voff[0]),
@@ -898,14 +902,21 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 #undef NB
               src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1);
             }
-            float w = 1.0f - C3;
-            C0 = __fmaf_rn(w, src.x, C0);
-            C1 = __fmaf_rn(w, src.y, C1);
-            C2 = __fmaf_rn(w, src.z, C2);
-            C3 = __fmaf_rn(w, src.w, C3);
-            // exact early termination: once A == 1.0f every later weight (1-A) is exactly 0,
-            // so no later sample can change C or A
-            if (C3 == 1.0f) m1 = m;
+            if (P.blend == SMK_BLEND_MAX) {  // GL_MAX (gluvvShadeMIP): no order, no termination
+              C0 = fmaxf(C0, src.x);
+              C1 = fmaxf(C1, src.y);
+              C2 = fmaxf(C2, src.z);
+              C3 = fmaxf(C3, src.w);
+            } else {
+              float w = 1.0f - C3;
+              C0 = __fmaf_rn(w, src.x, C0);
+              C1 = __fmaf_rn(w, src.y, C1);
+              C2 = __fmaf_rn(w, src.z, C2);
+              C3 = __fmaf_rn(w, src.w, C3);
+              // exact early termination: once A == 1.0f every later weight (1-A) is exactly 0,
+              // so no later sample can change C or A
+              if (C3 == 1.0f) m1 = m;
+            }
           }
 #undef QI
         }
@@ -1102,6 +1113,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
   opt_T &= 0xff;
   *why = nullptr;
   if (P.pert_on) { *why = "perturbation"; return hipErrorNotSupported; }
+  if (P.blend == SMK_BLEND_BACK_TO_FRONT) { *why = "back-to-front blend (slices stream front to back)"; return hipErrorNotSupported; }
   if (P.depth) { *why = "first-hit depth requested"; return hipErrorNotSupported; }  // (a register the fast path cannot spare)
   if (P.N[0] < 2 || P.N[1] < 2 || P.N[2] < 2) { *why = "volume thinner than 2 voxels"; return hipErrorNotSupported; }
   if (dtype == 1 && !P.n_in_w) { *why = "4-channel f32 voxels"; return hipErrorNotSupported; }

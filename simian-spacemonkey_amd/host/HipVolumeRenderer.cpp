@@ -3,6 +3,10 @@
 // the reference files cited inline.
 #include "HipVolumeRenderer.h"
 
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
 #include <cstdio>
 #include <iostream>
 
@@ -77,7 +81,16 @@ int HipVolumeRenderer::createVolume(int type, Volume *v, int nVols) {
 }
 
 int HipVolumeRenderer::createTLUT() {
-  tlut = new TLUT;
+  tlut = new HipTLUT;
+  return 1;
+}
+
+// TLUT::scaleAlpha (TLUT.cpp:138-154) up to, not including, its loadTransferTableRGBA() call
+int HipTLUT::scaleAlphaNoUpload(float sampleRate) {
+  if (lastSampleRate == sampleRate) return 0;
+  float alphaScale = lastSampleRate / sampleRate;
+  lastSampleRate = sampleRate;
+  for (int i = 0; i < _size; ++i) _rgba[i * _numElts + 3] = 1 - pow((1 - _rgba[i * _numElts + 3]), alphaScale);
   return 1;
 }
 
@@ -123,7 +136,20 @@ void HipVolumeRenderable::init() {
   } else {
     gluvv.volren.loadTLUT = 1;  // first draw() sends deptex/deptex2 (NV20VolRen3D.cpp:91-122)
   }
+  createNoiseTex(32, 32, 32);  // R8kVolRen3D_cpy.cpp:61 (constructor) -> :300-304
   go = 1;
+}
+
+// R8kVolRen3D_cpy::createNoiseTex (:2392-2436): srand(1), four draws per texel, no blur pass (its
+// loop runs zero times); the GL texture it fills is GL_REPEAT + GL_LINEAR -- smk_set_perturb's fetch
+void HipVolumeRenderable::createNoiseTex(int sx, int sy, int sz) {
+  noise.resize((size_t)sx * sy * sz * 4);
+  srand(1);
+  for (int i = 0; i < sz; ++i)
+    for (int j = 0; j < sy; ++j)
+      for (int k = 0; k < sx; ++k)
+        for (int e = 0; e < 4; ++e)
+          noise[(size_t)i * sx * sy * 4 + (size_t)j * sx * 4 + k * 4 + e] = (unsigned char)(((rand() / (float)RAND_MAX * .5) + .5 + 1.0 / 512) * 255);
 }
 
 void HipVolumeRenderable::draw() {
@@ -135,16 +161,28 @@ void HipVolumeRenderable::draw() {
   smk_ctx *c = volren->context();
   if (gluvv.volren.tlut && gluvv.dmode == GDM_V1 && !gluvv.volren.deptex) {
     // VolumeRenderable::draw (:50-54): opacity-correct the TLUT for the sample rate, re-send
-    if (volren->getColorMap()->scaleAlpha(gluvv.volren.sampleRate) || gluvv.volren.loadTLUT) {
+    // (TLUT::scaleAlpha itself re-uploads through GL and returns nothing, TLUT.h:45: the same
+    //  arithmetic without the upload, then one smk_set_tlut1d when anything changed)
+    if (volren->colorMap()->scaleAlphaNoUpload(gluvv.volren.sampleRate) | gluvv.volren.loadTLUT) {
       gluvv.volren.loadTLUT = 0;
       volren->loadTransferTableRGBA();
     }
   } else if (gluvv.volren.loadTLUT) {
     // TFWidgetRen raised loadTLUT after rasterising into deptex (TFWidgetRen1.cpp:232-242)
-    if (smk_set_tf2d(c, gluvv.volren.deptex, gluvv.volren.deptex2, gluvv.tf.ptexsz[0], gluvv.tf.ptexsz[1]))
-      std::cerr << "ERROR: HipVolumeRenderable::draw: " << smk_last_error(c) << std::endl;
+    // a table with several sheets along the third axis (gluvv.tf.ptexsz[2] > 1: what LevWidget::rasterize
+    // fills as tex[h][g][v][4], LevWidget.cpp:691-693, and the old widget called ptex,
+    // TFWidgetRen.cpp:779-845) is the dense 3-D transfer function; one sheet is the 2-D one x deptex2
+    int bad;
+    if (gluvv.tf.ptexsz[2] > 1) bad = smk_set_tf3d(c, gluvv.volren.deptex, gluvv.tf.ptexsz[0], gluvv.tf.ptexsz[1], gluvv.tf.ptexsz[2]);
+    else bad = smk_set_tf2d(c, gluvv.volren.deptex, gluvv.volren.deptex2, gluvv.tf.ptexsz[0], gluvv.tf.ptexsz[1]);
+    if (bad) std::cerr << "ERROR: HipVolumeRenderable::draw: " << smk_last_error(c) << std::endl;
     gluvv.volren.loadTLUT = 0;
   }
+  // noise-perturbed fetch (R8kVolRen3D_cpy.cpp:300-304 constants, :1590-1595 coordinates): the _cpy
+  // renderer, chosen at compile time in gluvv.cpp:164-198, always perturbs; as one renderer among the
+  // others this one follows gluvv.pert.on
+  if (gluvv.pert.on) smk_set_perturb(c, noise.data(), 32, gluvv.pert.weights, gluvv.pert.scales);
+  else smk_set_perturb(c, nullptr, 0, nullptr, nullptr);
   // clip-plane widget, orthogonal mode (NV20VolRen3D::setupClips, NV20VolRen3D.cpp:251-327)
   smk_set_clip(c, gluvv.clip.on && gluvv.clip.ortho, (int)gluvv.clip.oaxis, gluvv.clip.vpos);
   // free mode: glClipPlane(GL_CLIP_PLANE5, {0,0,-1,0}) under wmv * T(clip.pos) * clip.xform (:346-357).
@@ -162,9 +200,14 @@ void HipVolumeRenderable::draw() {
   } else {
     smk_set_clip_plane(c, 0, nullptr);
   }
+  // Phong of the platform's renderer: register combiners on the GeForce3 targets (NV20VolRen3D.cpp:634-806),
+  // the cube-map shader everywhere else (R8kVolRen3D.cpp:2620-2679, 2886-2902; renderer choice gluvv.cpp:141-199)
+  const bool nv20 = gluvv.plat == GPNV20 || gluvv.plat == GPNV202D;
   smk_shade sm = SMK_SHADE_NONE;
-  if (gluvv.shade == gluvvShadeDiff) sm = SMK_SHADE_R8K_DIFF;
-  if (gluvv.shade == gluvvShadeDSpec) sm = SMK_SHADE_R8K_DSPEC;
+  if (gluvv.shade == gluvvShadeDiff) sm = nv20 ? SMK_SHADE_NV20_DIFF : SMK_SHADE_R8K_DIFF;
+  if (gluvv.shade == gluvvShadeDSpec) sm = nv20 ? SMK_SHADE_NV20_DSPEC : SMK_SHADE_R8K_DSPEC;
+  // gluvvShadeMIP: glBlendEquationEXT(GL_MAX) around renderBricks (NV20VolRen3D.cpp:158-163)
+  smk_set_blend(c, gluvv.shade == gluvvShadeMIP ? SMK_BLEND_MAX : SMK_BLEND_FRONT_TO_BACK);
   smk_set_shading(c, sm, gluvv.light.pos, gluvv.env.eye, gluvv.env.at, gluvv.rinfo.xform, gluvv.light.intens, gluvv.light.amb);
   volren->renderVolume(gluvv.volren.sampleRate, mv);
   if (!volren->ok()) go = 0;

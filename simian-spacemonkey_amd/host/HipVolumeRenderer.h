@@ -14,11 +14,24 @@
 #include <vector>
 
 #include "../../include/smk.h"
-#ifndef SMK_USE_REFERENCE_HEADERS
+#ifdef SMK_USE_REFERENCE_HEADERS
+#include "gluvv.h"  // the reference's own: pulls in gluvvPrimitive.h, MetaVolume.h, TLUT.h
+#else
 #include "gluvv_compat.h"
 #endif
 
 enum { VolRenUnkown, VolRen2DTexture, VolRen3DTexture, VolRen3DExt };  // VolumeRenderer.h:64-69
+
+// The renderer's colour map.  TLUT::scaleAlpha (TLUT.cpp:138-154) ends in loadTransferTableRGBA(), a
+// GL colour-table upload, and returns nothing; this subclass reaches TLUT's protected members to do
+// the same opacity correction on the same fields without the GL call and says whether the table
+// changed (so the adapter knows when to send it through smk_set_tlut1d).  It adds no data member:
+// what gluvv.volren.tlut publishes is a plain TLUT to everyone else.
+class HipTLUT : public TLUT {
+ public:
+  HipTLUT() : TLUT() {}
+  int scaleAlphaNoUpload(float sampleRate);  // 1 = alphas were rescaled
+};
 
 class HipVolumeRenderer {
  public:
@@ -28,6 +41,7 @@ class HipVolumeRenderer {
   int createVolume(int type, Volume *v, int nVols);  // VolumeRenderer.cpp:128
   int createTLUT();                                  // always returns 1, as the reference (:214-219)
   TLUT *getColorMap() { return tlut; }
+  HipTLUT *colorMap() { return tlut; }  // the same object with the GL-free opacity correction
   // one frame; mv = column-major modelview as glGetDoublev returns it (VolumeRenderable.cpp:47-48)
   void renderVolume(float sampleRate, double mv[16]);
   // the frame of the last renderVolume: [height][width][4] premultiplied float RGBA
@@ -42,22 +56,24 @@ class HipVolumeRenderer {
   int upload(Volume *v, int n);
   smk_ctx *ctx;
   MetaVolume *m_vol;
-  TLUT *tlut;
+  HipTLUT *tlut;
   std::vector<float> fb;
   int failed;
 };
 
-class HipVolumeRenderable : public gluvvPrimitive {
+class HipVolumeRenderable final : public gluvvPrimitive {
  public:
   explicit HipVolumeRenderable(int device = 0) : volren(nullptr), go(0), device(device) {}
-  ~HipVolumeRenderable() override { delete volren; }
-  void init() override;
-  void draw() override;
+  ~HipVolumeRenderable() { delete volren; }  // (gluvvPrimitive's destructor is not virtual, gluvvPrimitive.h:26: delete through this type)
+  void init();  // virtual in gluvvPrimitive (gluvvPrimitive.h:29-30)
+  void draw();
   const float *framebuffer() const { return volren ? volren->framebuffer() : nullptr; }
   int running() const { return go; }
 
  private:
+  void createNoiseTex(int sx, int sy, int sz);  // R8kVolRen3D_cpy::createNoiseTex (:2392-2436)
   HipVolumeRenderer *volren;
   int go;
   int device;
+  std::vector<unsigned char> noise;  // [sz][sy][sx][4]
 };

@@ -1,125 +1,460 @@
 // gluvv_compat.h -- the slice of Simian's data model a renderer touches, declared with the SAME
-// names and meaning as the reference so the adapter below reads like a reference renderer and
-// can be compiled and tested without the reference tree (which needs GLUT/GLUI/WGL).
-// In a real integration this header is NOT used: the adapter includes the reference's own
-// MetaVolume.h / TLUT.h / gluvv.h / gluvvPrimitive.h instead.
+// names, types and member signatures as the reference so the adapter can be compiled and tested
+// without the reference tree (whose gluvv.h pulls in GLUT/GLUI through TFWindow.h/LTWidgetRen.h).
+// In a real integration this header is NOT used: the adapter is built with
+// -DSMK_USE_REFERENCE_HEADERS and includes the reference's own MetaVolume.h / TLUT.h / gluvv.h /
+// gluvvPrimitive.h instead.
 //
-//   Volume, MetaVolume ........ MetaVolume.h:18-170 (fields a renderer reads)
-//   TLUT ...................... TLUT.h:16-116, TLUT.cpp:26-36, 138-154
-//   gluvvGlobal (subset) ...... gluvv.h:29-275
-//   gluvvPrimitive ............ gluvvPrimitive.h:23-55
+//   Volume, MetaVolume ........ MetaVolume.h:18-170
+//   TLUT ...................... TLUT.h:16-116 (inline accessors :121-200), TLUT.cpp:26-42, 125-154
+//   gluvv structs + enums ..... gluvv.h:29-268
+//   gluvvPrimitive ............ gluvvPrimitive.h:23-55, gluvvPrimitive.cpp:101-167
+//
+// Rules this file keeps (tests/test_compat_signatures.py checks them against the reference text,
+// and compiles the adapter against the reference's real headers):
+//   * every class / struct / enum here exists in the reference under the same name;
+//   * every data member has the reference's type; every member function the reference's return
+//     type, parameter types and constness -- a SUBSET of the reference's members, never an addition;
+//   * enumerators keep the reference's order (their values cross the C ABI as integers).
+// What differs, and why it is harmless: member functions have inline bodies here (the reference
+// defines them in .cpp files that need OpenGL); TLUT::loadTransferTableRGBA uploads nothing (the
+// adapter sends the table through smk_set_tlut1d instead of the GL colour table).
 #pragma once
-#include <cmath>
-#include <cstring>
+#include <math.h>
+#include <string.h>
 
 class Volume {
  public:
-  int xiSize = 0, yiSize = 0, ziSize = 0;
-  float xfSize = 0, yfSize = 0, zfSize = 0;
-  int xiPos = 0, yiPos = 0, ziPos = 0;
-  float xfPos = 0, yfPos = 0, zfPos = 0;
-  unsigned char *currentData = nullptr;  // [z][y][x][nelts]
-  unsigned char *currentGrad = nullptr;  // [z][y][x][3] or null
+  Volume();
+  ~Volume();
+
+  int subVolNum;
+
+  int xiSize, yiSize, ziSize;
+  int xiVSize, yiVSize, ziVSize;
+  float xfSize, yfSize, zfSize;
+  float xfVSize, yfVSize, zfVSize;
+
+  int xiPos, yiPos, ziPos;
+  float xfPos, yfPos, zfPos;
+
+  unsigned char *dbData[2];
+  unsigned char *dbGrad[2];
+  unsigned char *currentData;  // [z][y][x][nelts]
+  unsigned char *currentGrad;  // [z][y][x][3] or null
+
+  int extradivs;
+
+  void *nativeData;
+
+  int timestep;
 };
+
+// (the reference's constructor also sets up its time-step cache; MetaVolume.cpp:36-75)
+inline Volume::Volume() { memset(this, 0, sizeof *this); }
+inline Volume::~Volume() {}  // voxel arrays belong to whoever loaded them (VolumeFiles.h: LoadedVolume)
 
 class MetaVolume {
  public:
-  Volume *volumes = nullptr;  // numSubVols bricks
-  int numSubVols = 0;
-  int nelts = 1;
-  int xiSize = 0, yiSize = 0, ziSize = 0;
-  float xfSize = 0, yfSize = 0, zfSize = 0;
+  MetaVolume();
+  ~MetaVolume();
+
+  int isValid(void) { return valid; };
+
+  int valid;
+
+  int dataType;
+  int dataEndian;
+
+  int tsteps;
+  int tstart;
+  int tstop;
+  int currentTStep;
+  int tstepCache;
+
+  int xiSize, yiSize, ziSize;
+  int xiVSize, yiVSize, ziVSize;
+  float xfSize, yfSize, zfSize;
+  float xfVSize, yfVSize, zfVSize;
+  float xSpc, ySpc, zSpc;
+  int numSubVols;
+  int nelts;
+  int nVelts;
+  int dims;
+
+  Volume *volumes;
+  Volume *wholeVol;
 };
+
+inline MetaVolume::MetaVolume() {
+  memset(this, 0, sizeof *this);
+  nelts = 1;  // "usualy 1" (MetaVolume.h:150)
+}
+inline MetaVolume::~MetaVolume() {}
 
 class TLUT {
  public:
-  explicit TLUT(int size = 256) : _size(size), _rgba(new float[4 * size]), lastSampleRate(1.0f) {
-    for (int n = 0; n < size; ++n) {
-      _rgba[4 * n] = _rgba[4 * n + 1] = _rgba[4 * n + 2] = n / (float)(size - 1.0);
-      _rgba[4 * n + 3] = (float)(1.0 / size);
-    }
-  }
-  ~TLUT() { delete[] _rgba; }
-  int GetSize() const { return _size; }
-  float *GetRGBA(int n) const { return &_rgba[4 * n]; }
-  void SetRGBA(int n, float r, float g, float b, float a) {
-    float *p = GetRGBA(n);
-    p[0] = r; p[1] = g; p[2] = b; p[3] = a;
-  }
-  // a <- 1-(1-a)^(lastSR/SR); returns true when the table changed (the reference re-uploads then)
-  bool scaleAlpha(float sampleRate) {
-    if (lastSampleRate == sampleRate) return false;
-    float alphaScale = lastSampleRate / sampleRate;
-    lastSampleRate = sampleRate;
-    for (int i = 0; i < _size; ++i) _rgba[4 * i + 3] = (float)(1 - pow((1 - _rgba[4 * i + 3]), alphaScale));
-    return true;
-  }
+  typedef enum {
+    _numElts = 4
+  } TLUTEnums;
 
- private:
-  int _size;
+  TLUT(const int size = 256);
+  ~TLUT();
+
+  void loadTransferTableRGBA();
+
+  void channelConstant(const int channelIndex, const float alpha);
+  void channelRamp(const int channelIndex, const int startIndex, const int stopIndex, const float startValue, const float stopValue);
+
+  void scaleAlpha(float sampleRate);
+
+  void alphaConstant(const float alpha) { channelConstant(3, alpha); }
+  void alphaRamp(const int startIndex, const int stopIndex, const float startValue, const float stopValue) { channelRamp(3, startIndex, stopIndex, startValue, stopValue); }
+
+  void rgbGrayScaleRamp();
+
+  inline int GetSize() const;
+  inline float *GetRGBA(const float t) const;
+  inline float *GetRGBA(const int n) const;
+  inline void SetRGBA(const int n, float r, float g, float b, float a);
+  inline void SetRGB(const int n, float r, float g, float b);
+  inline void SetAlpha(const int n, float a);
+
+ protected:
+  float *theTable;
   float *_rgba;
+  int _size;
+  float _alpha;
   float lastSampleRate;
+  float lastAlphaScale;
 };
 
-typedef enum { VolRenAxisUnknown, VolRenAxisXPos, VolRenAxisXNeg, VolRenAxisYPos, VolRenAxisYNeg, VolRenAxisZPos, VolRenAxisZNeg } VolRenMajorAxis;  // gluvv.h:136-144
-typedef enum { gluvvShadeUnknown, gluvvShadeAmb, gluvvShadeDiff, gluvvShadeDSpec, gluvvShadeFaux, gluvvShadeArb, gluvvShadeMIP } gluvvShade;
-typedef enum {
-  GDM_V1, GDM_V1G, GDM_V1GH, GDM_V2, GDM_V2G, GDM_V2GH, GDM_V3, GDM_V3G, GDM_V4, GDM_VGH, GDM_VGH_VG, GDM_VGH_V, GDM_UNKNOWN
-} gluvvDataMode;
-
-struct gluvvGlobal {
-  struct { unsigned int width = 512, height = 512; } win;
-  struct {
-    float eye[3] = {0, 0, -7}, at[3] = {0, 0, 0}, up[3] = {0, 1, 0};
-    float frustum[4] = {-.2f, .2f, -.2f, .2f};
-    float clip[2] = {1, 20};
-    int bgColor = 0;
-  } env;
-  struct { float pos[3] = {0, 0, -5}; float amb = .05f, intens = .75f; } light;
-  struct { float xform[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1}; float scale = 1; float trans[3] = {0, 0, 0}; } rinfo;
-  struct {
-    float sampleRate = 2.5f, interactSamp = .6f, goodSamp = 2.5f;
-    TLUT *tlut = nullptr;
-    unsigned char *deptex = nullptr, *deptex2 = nullptr;
-    int loadTLUT = 0, scaleAlphas = 1;
-    float gamma = 1;
-  } volren;
-  struct { int ptexsz[3] = {256, 256, 1}; int numelts = 4; } tf;
-  struct {
-    int on = 0, ortho = 1;
-    VolRenMajorAxis oaxis = VolRenAxisXPos;
-    float vpos[3] = {0, 0, 0};   // plane position in volume space (orthogonal mode)
-    float pos[3] = {0, 0, 0};    // plane position in world space (free mode)
-    float xform[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};  // its orientation
-  } clip;  // gluvvClip (gluvv.h:163-175), the fields the renderer reads
-  struct { int on = 0; float weights[10] = {.2f, 0, 0, 0}, scales[10] = {.2f, 2.1f, 4.5f, 8.7f}; } pert;
-  int picking = 0;
-  int reblend = 0;
-  MetaVolume *mv = nullptr;
-  gluvvShade shade = gluvvShadeFaux;
-  gluvvDataMode dmode = GDM_V1;
-};
-extern gluvvGlobal gluvv;  // "This needs to be declared in the main function!" (gluvv.h:270)
+inline TLUT::TLUT(const int size) {  // TLUT.cpp:26-36
+  _size = size;
+  _rgba = new float[_numElts * size];
+  theTable = new float[_numElts * size];
+  _alpha = (float)(1.0 / _size);
+  rgbGrayScaleRamp();
+  alphaConstant(_alpha);
+  lastSampleRate = 1.0f;
+  lastAlphaScale = 1.0f;
+}
+inline TLUT::~TLUT() {
+  delete[] _rgba;
+  delete[] theTable;
+}
+inline void TLUT::loadTransferTableRGBA() {  // TLUT.cpp:65-71 without the glColorTable call
+  for (int n = 0; n < _size; ++n) {
+    float *rgba = this->GetRGBA(n);
+    theTable[n * _numElts + 0] = rgba[0] * rgba[3];
+    theTable[n * _numElts + 1] = rgba[1] * rgba[3];
+    theTable[n * _numElts + 2] = rgba[2] * rgba[3];
+    theTable[n * _numElts + 3] = rgba[3];
+  }
+}
+inline void TLUT::channelConstant(const int channelIndex, const float alpha) {  // TLUT.cpp:112-123
+  for (int n = 0; n < _size; ++n) _rgba[n * _numElts + channelIndex] = alpha;
+}
+inline void TLUT::channelRamp(const int channelIndex, const int startIndex, const int stopIndex, const float startValue, const float stopValue) {  // :125-136
+  float denom = stopIndex - startIndex;
+  float range = stopValue - startValue;
+  for (int n = startIndex; n <= stopIndex; ++n) _rgba[n * _numElts + channelIndex] = startValue + range * (n - startIndex) / denom;
+}
+inline void TLUT::scaleAlpha(float sampleRate) {  // TLUT.cpp:138-154
+  if (lastSampleRate == sampleRate) return;
+  float alphaScale = lastSampleRate / sampleRate;
+  lastSampleRate = sampleRate;
+  for (int i = 0; i < _size; ++i) _rgba[i * _numElts + 3] = 1 - pow((1 - _rgba[i * _numElts + 3]), alphaScale);
+  loadTransferTableRGBA();
+}
+inline void TLUT::rgbGrayScaleRamp() {  // TLUT.cpp:192-199
+  for (int n = 0; n < _size; ++n) _rgba[n * _numElts] = _rgba[n * _numElts + 1] = _rgba[n * _numElts + 2] = n / (float)(_size - 1.0);
+}
+inline int TLUT::GetSize() const { return _size; }
+inline float *TLUT::GetRGBA(const float t) const {
+  int offset = (int)(t * (_size - 1));
+  return &(_rgba[offset * _numElts]);
+}
+inline float *TLUT::GetRGBA(const int n) const { return &(_rgba[n * _numElts]); }
+inline void TLUT::SetRGBA(const int n, float r, float g, float b, float a) {
+  SetRGB(n, r, g, b);
+  SetAlpha(n, a);
+}
+inline void TLUT::SetRGB(const int n, float r, float g, float b) {
+  int offset = n * _numElts;
+  _rgba[offset] = r;
+  _rgba[offset + 1] = g;
+  _rgba[offset + 2] = b;
+}
+inline void TLUT::SetAlpha(const int n, float a) {
+  int offset = n * _numElts;
+  _rgba[offset + 3] = a;
+}
 
 class gluvvPrimitive {
  public:
-  gluvvPrimitive() : next(nullptr) {}
-  virtual ~gluvvPrimitive() {}
-  virtual void init() {}
-  virtual void draw() {}
-  virtual int key(unsigned char, int, int) { return 0; }
-  virtual int special(int, int, int) { return 0; }
-  virtual int pick(int, int, int, float, float, float) { return 0; }
-  virtual int pick() { return 0; }
-  virtual int mouse(int, int, int, int) { return 1; }
-  virtual int move(int, int) { return 1; }
-  virtual int release() { return 0; }
-  void setNext(gluvvPrimitive *p) {  // LIFO insert (gluvvPrimitive.cpp:163-167)
-    p->next = next;
-    next = p;
-  }
-  gluvvPrimitive *getNext() { return next; }
+  gluvvPrimitive();
+  ~gluvvPrimitive();
+
+  virtual void init();
+  virtual void draw();
+  virtual int key(unsigned char k, int x, int y);
+  virtual int special(int k, int x, int y);
+  virtual int pick(int data1, int data2, int data3, float x, float y, float z);
+  virtual int pick();
+  virtual int mouse(int button, int state, int x, int y);
+  virtual int move(int x, int y);
+  virtual int release();
+
+  void setNext(gluvvPrimitive *p);
+  gluvvPrimitive *getNext();
+
+  void setName(const char *PName);
 
  private:
   gluvvPrimitive *next;
+  char *name;
 };
+
+// defaults of gluvvPrimitive.cpp:101-167
+inline gluvvPrimitive::gluvvPrimitive() : next(0), name(0) {}
+inline gluvvPrimitive::~gluvvPrimitive() {}  // NOT virtual in the reference either (gluvvPrimitive.h:26)
+inline void gluvvPrimitive::init() {}
+inline void gluvvPrimitive::draw() {}
+inline int gluvvPrimitive::key(unsigned char, int, int) { return 0; }
+inline int gluvvPrimitive::special(int, int, int) { return 0; }
+inline int gluvvPrimitive::pick(int, int, int, float, float, float) { return 0; }
+inline int gluvvPrimitive::pick() { return 0; }
+inline int gluvvPrimitive::mouse(int, int, int, int) { return 1; }
+inline int gluvvPrimitive::move(int, int) { return 1; }
+inline int gluvvPrimitive::release() { return 0; }
+inline void gluvvPrimitive::setNext(gluvvPrimitive *p) {  // LIFO insert (gluvvPrimitive.cpp:163-167)
+  p->next = next;
+  next = p;
+}
+inline gluvvPrimitive *gluvvPrimitive::getNext() { return next; }
+inline void gluvvPrimitive::setName(const char *) {}
+
+struct gluvvWindow {
+  unsigned int width;
+  unsigned int height;
+  unsigned int xPos;
+  unsigned int yPos;
+};
+
+struct gluvvEnv {
+  float eye[3];
+  float at[3];
+  float up[3];
+  float frustum[4];
+  float clip[2];
+  float diff[4];
+  float spec[4];
+  int bgColor;
+};
+
+struct gluvvLight {
+  float pos[3];
+  float startpos[3];
+  float color[3];
+  float amb;
+  float intens;
+  float mv[16];
+  float pj[16];
+  float xf[16];
+  int buffsz[2];
+  int shadow;
+  int softShadow;
+};
+
+struct gluvvRInfo {
+  float xform[16];
+  float scale;
+  float trans[3];
+};
+
+struct gluvvVolRen {
+  float sampleRate;
+  float interactSamp;
+  float goodSamp;
+  int shade;
+  TLUT *tlut;
+  unsigned char *deptex;
+  unsigned int deptexName;
+  unsigned char *deptex2;
+  unsigned int deptex2Name;
+  unsigned char *deptex3;
+  unsigned int deptex3Name;
+  int loadTLUT;
+  int scaleAlphas;
+  float gamma;
+  int timestep;
+};
+
+typedef enum {
+  VolRenAxisUnknown,
+  VolRenAxisXPos,
+  VolRenAxisXNeg,
+  VolRenAxisYPos,
+  VolRenAxisYNeg,
+  VolRenAxisZPos,
+  VolRenAxisZNeg
+} VolRenMajorAxis;
+
+struct gluvvTF {
+  int loadme;
+  int paintme;
+  int dropme;
+  int clearpaint;
+  int ptexsz[3];
+  int numelts;
+  int brushon;
+  float slider1;
+  float slider1hi;
+  float slider1lo;
+  float slider2;
+  int histOn;
+};
+
+struct gluvvClip {
+  int on;
+  int ortho;
+  VolRenMajorAxis oaxis;
+  float xform[16];
+  unsigned int pname;
+  float alpha;
+  float pos[3];
+  float vpos[3];
+  float dir[3];
+};
+
+struct gluvvPert {
+  int on;
+  int numHarm;
+  float weights[10];
+  float scales[10];
+};
+
+typedef enum {
+  NoBrush,
+  EllipseBrush,
+  AutoEllipseBrush,
+  TriangleBrush,
+  OneDBrush,
+  AutoOneDBrush
+} gluvvBrush;
+
+struct gluvvProbe {
+  float vpos[3];
+  float slider;
+  gluvvBrush brush;
+};
+
+typedef enum {
+  gluvvShadeUnknown,
+  gluvvShadeAmb,
+  gluvvShadeDiff,
+  gluvvShadeDSpec,
+  gluvvShadeFaux,
+  gluvvShadeArb,
+  gluvvShadeMIP
+} gluvvShade;
+
+typedef enum {
+  GPGineric,
+  GPOctane,
+  GPOctane2,
+  GPInfinite,
+  GPNV15,
+  GPNV20,
+  GPNV202D,
+  GPWildcat,
+  GPATI8K
+} gluvvPlatform;
+
+typedef enum {
+  GDM_V1,
+  GDM_V1G,
+  GDM_V1GH,
+  GDM_V2,
+  GDM_V2G,
+  GDM_V2GH,
+  GDM_V3,
+  GDM_V3G,
+  GDM_V4,
+  GDM_VGH,
+  GDM_VGH_VG,
+  GDM_VGH_V,
+  GDM_UNKNOWN
+} gluvvDataMode;
+
+typedef enum {
+  GB_NONE,
+  GB_UNDER,
+  GB_OVER,
+  GB_ZERO
+} gluvvBlend;
+
+struct gluvvGlobal {
+  int debug;
+  gluvvWindow win;
+  gluvvEnv env;
+  gluvvLight light;
+  gluvvRInfo rinfo;
+  gluvvPlatform plat;
+  int picking;
+  gluvvVolRen volren;
+  gluvvTF tf;
+  gluvvClip clip;
+  gluvvProbe probe;
+  int mprobe;
+  MetaVolume *mv;
+  MetaVolume *mv1;
+  MetaVolume *mv2;
+  MetaVolume *mv3;
+  int mainWindow;
+  gluvvShade shade;
+  gluvvDataMode dmode;
+  gluvvBlend reblend;
+  gluvvPert pert;
+};
+
+extern gluvvGlobal gluvv;  // "This needs to be declared in the "main" function!" (gluvv.h:270-273)
+
+// initGluvv()'s defaults for the fields a renderer reads (gluvv.cpp:240-368; gluvvui.cpp:213-267 for
+// the perturbation block).  A stand-alone driver calls this once; inside Simian initGluvv does.
+inline void gluvvCompatDefaults(gluvvGlobal &g) {
+  memset(&g, 0, sizeof g);
+  g.win.width = g.win.height = 512;
+  g.env.eye[2] = -7;
+  g.env.up[1] = 1;
+  g.env.frustum[0] = g.env.frustum[2] = -.2f;
+  g.env.frustum[1] = g.env.frustum[3] = .2f;
+  g.env.clip[0] = 1;
+  g.env.clip[1] = 20;
+  g.light.pos[2] = -5;
+  g.light.amb = .05f;
+  g.light.intens = .75f;
+  g.light.buffsz[0] = g.light.buffsz[1] = 1024;
+  for (int i = 0; i < 4; ++i) g.rinfo.xform[5 * i] = g.clip.xform[5 * i] = 1;
+  g.rinfo.scale = 1;
+  g.volren.sampleRate = g.volren.goodSamp = 2.5f;
+  g.volren.interactSamp = .6f;
+  g.volren.scaleAlphas = 1;
+  g.volren.gamma = 1;
+  g.tf.ptexsz[0] = g.tf.ptexsz[1] = 256;
+  g.tf.ptexsz[2] = 1;
+  g.tf.numelts = 4;
+  g.tf.slider1 = g.tf.slider1hi = 1;
+  g.clip.ortho = 1;
+  g.clip.oaxis = VolRenAxisXPos;
+  g.pert.weights[0] = .2f;
+  g.pert.scales[0] = .2f;
+  g.pert.scales[1] = 2.1f;
+  g.pert.scales[2] = 4.5f;
+  g.pert.scales[3] = 8.7f;
+  g.plat = GPGineric;
+  g.shade = gluvvShadeFaux;
+  g.dmode = GDM_V1;
+  g.reblend = GB_NONE;
+}

@@ -1,6 +1,8 @@
 // Drives the host-side mirror the way Simian's main() drives a renderer (gluvv.cpp:141-199,
 // 518-525, 593-597): fill `gluvv`, new the primitive, link it, init() once, draw() per frame.
 // usage: adapter_main <vol.u8 nx ny nz nelts> <grad.u8|-> <deptex.rgba|-> <W> <H> <rate> <shade 0|3> <xform16...> <out.f32>
+//        ... [key=value ...] after <out.f32>: dmode=<gluvvDataMode>, plat=<gluvvPlatform>, tfsize=<sv>,<sg>,<sh> (a table of
+//        several sheets is the dense 3-D transfer function), deptex2=<file>, pert=<w0>,<w1>,<s0>,<s1> (gluvv.pert, on)
 //        adapter_main <dataset.trex 0 0 0 1> ...   the volume comes from disk the way `gluvv data.trex` loads it
 //                                                   (MetaVolume(file) + readAll(tstart), gluvv.cpp:160-176)
 #include <cstdio>
@@ -30,6 +32,7 @@ int main(int argc, char **argv) {
     fprintf(stderr, "bad usage\n");
     return 2;
   }
+  gluvvCompatDefaults(gluvv);  // what initGluvv() does (gluvv.cpp:240-368)
   int a = 1;
   const std::string first = argv[1];
   const bool from_trex = first.size() > 5 && first.substr(first.size() - 5) == ".trex";
@@ -53,6 +56,22 @@ int main(int argc, char **argv) {
   gluvv.shade = (gluvvShade)atoi(argv[a++]);
   for (int i = 0; i < 16; ++i) gluvv.rinfo.xform[i] = (float)atof(argv[a++]);
   const char *out = argv[a++];
+  std::vector<unsigned char> dep2;
+  int dmode_arg = -1;
+  for (; a < argc; ++a) {  // optional state a GUI session would have set
+    const std::string kv = argv[a];
+    const size_t eq = kv.find('=');
+    if (eq == std::string::npos) continue;
+    const std::string k = kv.substr(0, eq), v = kv.substr(eq + 1);
+    if (k == "dmode") dmode_arg = atoi(v.c_str());
+    else if (k == "plat") gluvv.plat = (gluvvPlatform)atoi(v.c_str());
+    else if (k == "tfsize") sscanf(v.c_str(), "%d,%d,%d", &gluvv.tf.ptexsz[0], &gluvv.tf.ptexsz[1], &gluvv.tf.ptexsz[2]);
+    else if (k == "deptex2") dep2 = slurp(v.c_str());
+    else if (k == "pert") {
+      gluvv.pert.on = 1;
+      sscanf(v.c_str(), "%f,%f,%f,%f", &gluvv.pert.weights[0], &gluvv.pert.weights[1], &gluvv.pert.scales[0], &gluvv.pert.scales[1]);
+    }
+  }
   if (!from_trex && vol.size() != (size_t)nx * ny * nz * ne) {
     fprintf(stderr, "volume size mismatch\n");
     return 2;
@@ -69,10 +88,11 @@ int main(int argc, char **argv) {
   mv.numSubVols = 1;
   mv.nelts = ne;
   gluvv.mv = from_trex ? &loaded.mv : &mv;
-  gluvv.dmode = ne == 1 ? GDM_V1 : GDM_VGH;
+  gluvv.dmode = dmode_arg >= 0 ? (gluvvDataMode)dmode_arg : (ne == 1 ? GDM_V1 : GDM_VGH);
   const float fr = 0.5f / 7;
   gluvv.env.frustum[0] = -fr; gluvv.env.frustum[1] = fr; gluvv.env.frustum[2] = -fr; gluvv.env.frustum[3] = fr;
   if (!dep.empty()) gluvv.volren.deptex = dep.data();
+  if (!dep2.empty()) gluvv.volren.deptex2 = dep2.data();
 
   gluvvPrimitive renderables;                 // "Dummy Node" list head (gluvv.cpp:252)
   HipVolumeRenderable *r = new HipVolumeRenderable(0);

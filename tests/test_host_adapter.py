@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "host", "adapter_main")
 
 
-def _run(tmp_path, sc, shade, rate, deptex):
+def _run(tmp_path, sc, shade, rate, deptex, extra=()):
     vol = tmp_path / "vol.u8"
     sc.data.tofile(vol)
     grad = "-"
@@ -28,7 +28,7 @@ def _run(tmp_path, sc, shade, rate, deptex):
     out = tmp_path / "frame.f32"
     nx, ny, nz = sc.dims
     cmd = [EXE, str(vol), str(nx), str(ny), str(nz), str(sc.nelts), str(grad), str(dep),
-           str(sc.width), str(sc.height), repr(rate), str(shade)] + [repr(float(v)) for v in sc.xform] + [str(out)]
+           str(sc.width), str(sc.height), repr(rate), str(shade)] + [repr(float(v)) for v in sc.xform] + [str(out)] + list(extra)
     p = subprocess.run(cmd, capture_output=True, text=True)
     return p, out
 
@@ -68,6 +68,55 @@ def test_vgh_path_like_nv20volren3d(tmp_path, O):
     got = np.fromfile(out, np.float32).reshape(sc.height, sc.width, 4)
     ref = sc.render()
     assert ref[..., 3].max() > 0.05 and np.abs(got - ref).max() <= 1e-4
+
+
+@pytest.mark.gpu
+def test_cfg5_through_the_renderer_slot(tmp_path, O):
+    """BASELINE config 5 through HipVolumeRenderable::init()/draw(): two merged fields (dmode V2G), a
+    transfer-function table of 16 sheets (gluvv.tf.ptexsz[2] > 1: the dense 3-D table), gluvv.pert
+    switched on -- the adapter makes createNoiseTex's texture itself (srand(1), libc rand) -- and the
+    cube-map Phong.  The CPU checker gets the same state, its noise from its own rand() clone."""
+    import _scenes as S
+    nx, ny, nz = 40, 36, 32
+    rng = np.random.default_rng(77)
+    z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    r2 = ((x - 20) ** 2 + (y - 18) ** 2 + (z - 16) ** 2) ** .5
+    f = np.stack([np.clip(255 - r2 * 11 + rng.normal(0, 3, x.shape), 0, 255),
+                  np.clip(np.sin(x * .35) * np.cos(y * .3) * 90 + 120 + rng.normal(0, 3, x.shape), 0, 255)], -1).astype(np.uint8)
+    merged, nrm = O.merge_addg(f)               # MetaVolume::mergeMV + addG, as initData leaves gluvv.mv
+    sc = O.Scene(merged, grad=nrm)
+    sc.tf_mode, sc.tf3d = 2, S.tf3d_dense()
+    sc.xform = O.rotation((1, 1, 0), 30)
+    sc.width = sc.height = 56
+    sc.steps, sc.sample_rate, sc.shade_mode = 0, 2.5, 1
+    sc.noise, sc.pert_w, sc.pert_s = O.noise_tex(32), (.05, .03, 0, 0), (.2, 2.1, 4.5, 8.7)
+    p, out = _run(tmp_path, sc, 3, 2.5, sc.tf3d, extra=["dmode=4", "tfsize=16,16,16", "pert=0.05,0.03,0.2,2.1"])
+    assert p.returncode == 0, p.stderr
+    got = np.fromfile(out, np.float32).reshape(sc.height, sc.width, 4)
+    ref = sc.render()
+    assert ref[..., 3].max() > 0.05 and np.abs(got - ref).max() <= 1e-4
+    # and it is the perturbation that was rendered: the unperturbed frame differs visibly
+    sc.noise = None
+    assert np.abs(sc.render() - ref).max() > 1e-2
+
+
+@pytest.mark.gpu
+def test_nv20_platform_selects_the_register_combiner_phong(tmp_path, O):
+    """gluvv.plat = GPNV20: the renderer Simian would have picked is NV20VolRen3D (gluvv.cpp:141-199),
+    whose Phong is the register-combiner one; third-axis table deptex2 forwarded as well."""
+    sc = make_scene("cfg4", n=24, size=40, pose="rot", shade=2)
+    sc.steps, sc.sample_rate = 0, 2.5
+    raw = sc.tf_vg
+    sc.tf_vg = O.copy_scale(raw, 2.5)
+    d2 = tmp_path / "deptex2.rgba"
+    sc.tf_h.tofile(d2)
+    p, out = _run(tmp_path, sc, 3, 2.5, raw, extra=["plat=5", "deptex2=%s" % d2])
+    assert p.returncode == 0, p.stderr
+    got = np.fromfile(out, np.float32).reshape(sc.height, sc.width, 4)
+    ref = sc.render()
+    assert ref[..., 3].max() > 0.05 and np.abs(got - ref).max() <= 1e-4
+    sc.shade_mode = 1
+    assert np.abs(sc.render() - ref).max() > 1e-3   # (the two Phong variants are told apart)
 
 
 @pytest.mark.gpu

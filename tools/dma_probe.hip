@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <vector>
 
@@ -162,6 +163,104 @@ __global__ void probe_rows(const char *buf, int nchunks, int nwaves, int active_
   if (lane == 0) cycles[gw] = t1 - t0;
 }
 
+
+// strip-major layout [s][ustrip][v][SWU units of 16 B]: a window = NSTR strips x ROWS rows; every
+// wave-instruction reads 1 KiB CONTIGUOUS (64/SWU rows of one strip), a strip's rows are one
+// contiguous run of ROWS * SWU * 16 bytes; strips are Dv rows apart, slices 16 MiB apart.
+// NT: the DMA carries the nt cache policy.
+template <int SWU, int NT>
+__global__ void probe_strips(const char *buf, int nslices, int nwaves, int nstr, int rows, long long *cycles) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = blockIdx.x * nwaves + wave;
+  const unsigned ring = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)smem + wave * 32 * 1024;
+  constexpr int RPI = 64 / SWU;            // rows per wave-instruction
+  constexpr unsigned ROWB = SWU * 16;      // bytes per strip row
+  const size_t strip_stride = (size_t)1024 * ROWB, slice_stride = (size_t)16384 * 1024;
+  const int ipr = (rows + RPI - 1) / RPI;  // instructions per strip
+  const int tx = blockIdx.x % 16, ty = (blockIdx.x / 16) % 16;
+  const size_t origin = (size_t)(tx * 32 * 16 / ROWB) * strip_stride + (size_t)(ty * 24 + 5) * ROWB;
+  const int phase = (int)((blockIdx.x * 37u) % 997u);
+  const unsigned voff = lane * 16u;
+  long long t0 = __builtin_amdgcn_s_memtime();
+  unsigned keep;
+  int issued = 0;
+  for (int sl = 0; sl < nslices; ++sl) {
+    const char *sbase = buf + (size_t)((sl + phase) % 1000) * slice_stride + origin;
+    for (int i = wave; i < nstr * ipr; i += nwaves) {
+      const int j = i / ipr, r = i - j * ipr;
+      const char *src = sbase + (size_t)j * strip_stride + (size_t)(r * RPI) * ROWB;
+      const int rows_here = min(RPI, rows - r * RPI);
+      const unsigned dst = ring + (unsigned)(issued & 31) * 1024;
+      if (lane < rows_here * SWU) {
+        if (NT)
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(voff), "s"(dst), "s"(src) : "memory");
+        else
+          asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                       : "=&s"(keep) : "v"(voff), "s"(dst), "s"(src) : "memory");
+      }
+      ++issued;
+      if ((issued & 7) == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  long long t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cycles[gw] = t1 - t0;
+}
+
+// the same strip-major HBM layout, but the LDS image stays ROW-major over the window (pitch = nstr * SWU
+// units): consecutive lanes walk along a window row, i.e. across strips -- every wave-instruction reads
+// 64/SWU pieces of SWU*16 B from up to nstr different strips.  Same bytes as probe_strips, different grouping.
+template <int SWU>
+__global__ void probe_strips_rm(const char *buf, int nslices, int nwaves, int nstr, int rows, long long *cycles) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = blockIdx.x * nwaves + wave;
+  const unsigned ring = (unsigned)(size_t)(__attribute__((address_space(3))) const void *)smem + wave * 32 * 1024;
+  constexpr unsigned ROWB = SWU * 16;
+  const size_t strip_stride = (size_t)1024 * ROWB, slice_stride = (size_t)16384 * 1024;
+  const int pitch = nstr * SWU, units = rows * pitch, ninstr = (units + 63) / 64;
+  const int tx = blockIdx.x % 16, ty = (blockIdx.x / 16) % 16;
+  const size_t origin = (size_t)(tx * 32 * 16 / ROWB) * strip_stride + (size_t)(ty * 24 + 5) * ROWB;
+  const int phase = (int)((blockIdx.x * 37u) % 997u);
+  long long t0 = __builtin_amdgcn_s_memtime();
+  unsigned keep;
+  int issued = 0;
+  // per-lane source offsets of this wave's instructions (static: the window shape never changes)
+  unsigned voff[8];
+  bool okk[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int i = wave + q * nwaves;
+    const int g = 64 * i + lane;
+    const int row = g / pitch, col = g - row * pitch;
+    voff[q] = (unsigned)((col / SWU) * strip_stride + (size_t)row * ROWB + (col % SWU) * 16);
+    okk[q] = i < ninstr && g < units;
+  }
+  for (int sl = 0; sl < nslices; ++sl) {
+    const char *src = buf + (size_t)((sl + phase) % 1000) * slice_stride + origin;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (wave + q * nwaves >= ninstr) break;
+      const unsigned dst = ring + (unsigned)(issued & 31) * 1024;
+      if (okk[q])
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff[q]), "s"(dst), "s"(src) : "memory");
+      ++issued;
+      if ((issued & 7) == 0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  long long t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) cycles[gw] = t1 - t0;
+}
+
+template <int SWU, int NT>
+static int run_strips(const char *buf, int nwaves, int wgs, int nstr, int rows, int nslices, long long *d_cyc);
+
 #define CK(x)                                                      \
   do {                                                             \
     hipError_t e_ = (x);                                           \
@@ -250,6 +349,52 @@ static int run_rows(const char *buf, int nwaves, int wgs, int active, int nchunk
   return 0;
 }
 
+template <int SWU, int NT>
+static int run_strips(const char *buf, int nwaves, int wgs, int nstr, int rows, int nslices, long long *d_cyc) {
+  auto k = probe_strips<SWU, NT>;
+  size_t lds = (size_t)nwaves * 32 * 1024;
+  CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k, dim3(wgs), dim3(nwaves * 64), lds, 0, buf, nslices, nwaves, nstr, rows, d_cyc);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  hipLaunchKernelGGL(k, dim3(wgs), dim3(nwaves * 64), lds, 0, buf, nslices, nwaves, nstr, rows, d_cyc);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  double bytes = (double)wgs * nslices * nstr * rows * SWU * 16.0;
+  printf("strips   %d strips x %2d rows x %3d B (runs of %5d B)  nt %d  waves/WG %d: %7.3f ms  %7.1f GB/s chip (source bytes)\n", nstr, rows,
+         SWU * 16, rows * SWU * 16, NT, nwaves, ms, bytes / ms / 1e6);
+  fflush(stdout);
+  return 0;
+}
+
+template <int SWU>
+static int run_strips_rm(const char *buf, int nwaves, int wgs, int nstr, int rows, int nslices, long long *d_cyc) {
+  auto k = probe_strips_rm<SWU>;
+  size_t lds = (size_t)nwaves * 32 * 1024;
+  CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL(k, dim3(wgs), dim3(nwaves * 64), lds, 0, buf, nslices, nwaves, nstr, rows, d_cyc);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  hipLaunchKernelGGL(k, dim3(wgs), dim3(nwaves * 64), lds, 0, buf, nslices, nwaves, nstr, rows, d_cyc);
+  CK(hipEventRecord(e1));
+  CK(hipDeviceSynchronize());
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  double bytes = (double)wgs * nslices * nstr * rows * SWU * 16.0;
+  printf("strips-rm %d strips x %2d rows x %3d B, row-major LDS image  waves/WG %d: %7.3f ms  %7.1f GB/s chip (source bytes)\n", nstr, rows,
+         SWU * 16, nwaves, ms, bytes / ms / 1e6);
+  fflush(stdout);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   size_t bytes = (size_t)17 << 30;
   char *buf;
@@ -258,6 +403,33 @@ int main(int argc, char **argv) {
   long long *d_cyc;
   CK(hipMalloc((void **)&d_cyc, 8 * 65536));
   const int nchunks = 8192;  // 8 MiB per wave
+
+  if (argc > 1 && !strcmp(argv[1], "strips2")) {
+    for (int rep = 0; rep < 2; ++rep) {
+      if (run_rows<2, 1>(buf, 4, 256, 30, 8192 / 4, d_cyc)) return 1;
+      if (run_strips<4, 0>(buf, 4, 256, 12, 35, 400, d_cyc)) return 1;
+      if (run_strips_rm<4>(buf, 4, 256, 12, 35, 400, d_cyc)) return 1;
+      if (run_strips<8, 0>(buf, 4, 256, 7, 35, 400, d_cyc)) return 1;
+      if (run_strips_rm<8>(buf, 4, 256, 7, 35, 400, d_cyc)) return 1;
+      if (run_strips_rm<8>(buf, 4, 256, 6, 35, 400, d_cyc)) return 1;
+      if (run_strips_rm<2>(buf, 4, 256, 24, 35, 400, d_cyc)) return 1;
+    }
+    return 0;
+  }
+  if (argc > 1 && !strcmp(argv[1], "strips")) {
+    // the slice-ring kernel's north-star window (44 x 35 voxels of 16 B) in three HBM layouts
+    for (int nw : {2, 4}) {
+      if (run_rows<2, 1>(buf, nw, 256, 30, 8192 / nw, d_cyc)) return 1;          // row-major: 480-B pieces 16 KiB apart
+      if (run_strips<4, 0>(buf, nw, 256, 12, 35, 400, d_cyc)) return 1;          // 4-voxel strips
+      if (run_strips<4, 1>(buf, nw, 256, 12, 35, 400, d_cyc)) return 1;
+      if (run_strips<8, 0>(buf, nw, 256, 7, 35, 400, d_cyc)) return 1;           // 8-voxel strips
+      if (run_strips<8, 1>(buf, nw, 256, 7, 35, 400, d_cyc)) return 1;
+      if (run_strips<16, 0>(buf, nw, 256, 4, 35, 400, d_cyc)) return 1;          // 16-voxel strips
+      if (run_strips<4, 0>(buf, nw, 256, 12, 48, 400, d_cyc)) return 1;          // whole 16-row instructions
+      if (run_strips<8, 0>(buf, nw, 256, 6, 40, 400, d_cyc)) return 1;
+    }
+    return 0;
+  }
   for (int nw : {1, 2, 4}) {   // scattered row pieces from cache (2 slices re-read) against HBM
     if (run_rows<2, 1>(buf, nw, 256, 32, nchunks / nw, d_cyc, 2)) return 1;
     if (run_rows<2, 1>(buf, nw, 256, 30, nchunks / nw, d_cyc, 2)) return 1;
