@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the volume ray-march hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N=1: run directly)
+    python bench.py --gpus N --steps K --warmup W            (N>1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Metric (BASELINE.json): Msamples/s (+ fps) of one frame of the 512^3 VGH volume at
@@ -218,6 +218,29 @@ def cpu_baseline(vghf, nrm, tf_path, size, planes, xform, mv, gpu_frame, budget_
             "host_cpus": os.cpu_count(), "parity_max_abs_err_vs_gpu": err}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this very command under
+    torch.distributed.run (one process per GPU), relay their output and exit with their code.  Runs
+    before anything touches the GPU.  On a box with fewer than N GPUs the ranks rehearse on cuda:0
+    (SMK_BENCH_REHEARSE=1: plumbing only, labelled as such on the JSON line)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if torch.cuda.device_count() < n:      # (counting devices does not initialise the GPU)
+        env["SMK_BENCH_REHEARSE"] = "1"
+        if n > 6:
+            print("bench.py: %d ranks cannot share one GPU (process guard); refusing" % n, file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,6 +254,8 @@ def main():
     ap.add_argument("--no-north-star", action="store_true")
     ap.add_argument("--north-star-volume", type=int, default=1024)
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -246,8 +271,10 @@ def main():
         else:
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if world != a.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
+    if world != a.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE %d: refusing to report a number for the wrong rank count" % (a.gpus, world), file=sys.stderr)
+        sys.exit(2)
 
     pkg = load_package()
     from simian_spacemonkey_amd import sortlast  # noqa: F401
@@ -270,10 +297,47 @@ def main():
     if world > 1:
         def march(ptr, stream):
             r.render_device(ptr, None, stream)
+            return r.last_frame_id()
+
+        def repair(frame_id, ptr, stream):
+            """a frame the slice-ring kernel flagged is rendered again by the gather kernel, on this rank
+            alone, before its layer is exchanged"""
+            if not r.frame_failed(frame_id):
+                return False
+            r.set_option("kernel", 1)
+            r.render_device(ptr, None, stream)
+            torch.cuda.synchronize()
+            r.set_option("kernel", a.kernel)
+            return True
 
         def over(layers, order_, out_tile, stream):
             r.composite_over_device(layers.data_ptr(), world, order_, layers.shape[1], out_tile.data_ptr(), stream)
-        cstate = (sortlast.Pipeline(march, over, npix, via_host=rehearse), r.shard_order(world))
+        # the merge: behind the C ABI (smk_exchange_*: grouped ncclSend/ncclRecv direct send + ordered over +
+        # gather, csrc/smk_exchange.hip) wherever every rank has its own GPU; the rehearsal on one GPU
+        # (RCCL does not run two ranks on one device) goes through torch.distributed/gloo instead
+        exchange_mode, xchg = "torch.distributed all_to_all_single + gather (gloo, rehearsal)", None
+        if not rehearse:
+            ok = 1
+            try:
+                uid = [pkg.exchange_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                xchg = pkg.Exchange(r, rank, world, npix, id=uid[0])
+            except Exception as e:  # noqa: BLE001  (reported on the JSON line, never silent)
+                ok, why = 0, str(e)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                exchange_mode = "smk_exchange (C ABI): RCCL grouped ncclSend/ncclRecv direct send + ordered over + gather"
+            else:
+                if xchg is not None:
+                    xchg.close()
+                xchg = None
+                exchange_mode = "torch.distributed all_to_all_single + gather over RCCL (smk_exchange unavailable on some rank%s)" % (
+                    ": " + why if not ok else "")
+        if xchg is not None:
+            cstate = (sortlast.ExchangePipeline(march, xchg, npix, rank, frame_check=repair), r.shard_order(world))
+        else:
+            cstate = (sortlast.Pipeline(march, over, npix, via_host=rehearse, frame_check=repair), r.shard_order(world))
         if rank != 0:
             del vghf, nrm
             vghf = nrm = None
@@ -312,6 +376,15 @@ def main():
                            "algorithmic_bytes_per_launch": alg_bytes,
                            "note": "this rank's shard; %d^3 f32 working set is VALU/LDS-bound by "
                                    "construction (BASELINE.md sec. 2), see north_star" % n}
+    failures = int(r.stat("slab_failures"))
+    if world > 1:
+        out["rccl_ranks"] = 0 if rehearse else world
+        out["exchange"] = exchange_mode
+        out["frames_repaired"] = int(cstate[0].repaired)
+        ft = torch.tensor([failures, out["frames_repaired"]], dtype=torch.int64, device="cuda" if not rehearse else "cpu")
+        dist.all_reduce(ft, op=dist.ReduceOp.SUM)
+        failures, out["frames_repaired"] = int(ft[0].item()), int(ft[1].item())
+    out["slab_failures"] = failures       # slice-ring frames flagged invalid during the run, all ranks (must be 0)
     if rehearse:
         out["data"] = "synthetic; REHEARSAL (all ranks on cuda:0, gloo through host memory): not a benchmark number"
     if world > 1:
@@ -360,11 +433,17 @@ def main():
                          # normal bytes per voxel the Phong term reads
                          "frac_on_vgh_bytes_only": (alg2 - 3.0 * nn_ ** 3) / (kms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS if kms2 > 0 else 0.0},
             "kernel": {1: "gather", 2: "slab-staged"}.get(kernel2, str(kernel2))}
+    bad = out["slab_failures"] != 0 or r.stat("slab_retries") != 0
     if rank == 0:
         print(json.dumps(out))
+    if world > 1 and cstate is not None and hasattr(cstate[0], "x"):
+        cstate[0].x.close()
     r.close()
     if world > 1:
         dist.destroy_process_group()
+    if bad:   # a frame the slice-ring kernel flagged would make the timing meaningless: fail loudly
+        print("bench.py: slice-ring kernel flagged %d frame(s)" % out["slab_failures"], file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

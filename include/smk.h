@@ -140,10 +140,51 @@ int smk_render(smk_ctx *ctx, float *rgba_out, float *depth_out);
 /* same with DEVICE output pointers; asynchronous on `stream` (a hipStream_t, NULL = default) */
 int smk_render_device(smk_ctx *ctx, void *d_rgba, void *d_depth, void *stream);
 
+/* Frames in flight (no reference equivalent: the reference renders synchronously).  smk_render_device
+ * only enqueues; the slice-ring kernel reports a protocol time-out or a window outside its host bound
+ * through a per-frame status word.  smk_last_frame_id: id of the frame the last smk_render_device call
+ * enqueued (1, 2, ...).  smk_frame_failed: call after synchronising with that frame's stream; 1 = the
+ * frame was flagged and must be rendered again (option "kernel" = 1 renders it on the gather kernel),
+ * 0 = valid.  Answers for the last 8 frames.  A flagged frame nobody asked about makes the NEXT render
+ * call fail; the synchronous smk_render re-renders such a frame itself.  Both are counted
+ * (smk_get_stat "slab_failures" / "slab_retries") so a test or a benchmark can require zero. */
+long long smk_last_frame_id(smk_ctx *ctx);
+int smk_frame_failed(smk_ctx *ctx, long long frame_id);
+
 /* sort-last merge: out = layer[order[0]] over layer[order[1]] over ...; layers are
  * premultiplied RGBA tiles of npix pixels, DEVICE pointers, layer l at layers + l*npix*4 floats. */
 int smk_composite_over_device(smk_ctx *ctx, const void *d_layers, int nlayers, const int *order,
                               int npix, void *d_out, void *stream);
+
+/* ---- the sort-last merge in C (no reference equivalent): one object per rank = per
+ * context / GPU.  Direct send of the 1/P image tiles (grouped ncclSend/ncclRecv over xGMI), ordered
+ * over of the P layers in smk_shard_order's order, finished tiles gathered on rank 0.
+ *   RCCL transport (id != NULL): one process per GPU.  Rank 0 makes the 128-byte communicator id
+ *     (smk_exchange_unique_id = ncclGetUniqueId) and hands it to the other ranks by whatever channel
+ *     the host has; smk_exchange_create is then collective (ncclCommInitRank).  librccl is opened at
+ *     run time.
+ *   in-process transport (id == NULL): the ranks are contexts of ONE process (a C++ host that owns
+ *     several GPUs): create all, smk_exchange_connect_local, then smk_exchange_frame_local per frame.
+ * A rank renders frame i into smk_exchange_partial(x, i & 1) -- [npix][4] floats, device -- after
+ * smk_exchange_acquire(x, i & 1, render_stream), and marks it with smk_exchange_rendered(x, i & 1,
+ * render_stream); smk_exchange_frame enqueues that frame's merge on the exchange's own stream behind
+ * that mark and returns at once, so frame i's merge overlaps frame i+1's ray-marching (which may
+ * already be enqueued: a host checks smk_frame_failed for frame i in between).  d_frame ([npix][4], rank 0 only) receives the merged frame;
+ * smk_exchange_wait makes a stream wait for everything enqueued so far.  The context must have been
+ * sharded with the same rank / nranks (smk_set_shard). */
+typedef struct smk_exchange smk_exchange;
+#define SMK_EXCHANGE_ID_BYTES 128
+int smk_exchange_unique_id(unsigned char id[SMK_EXCHANGE_ID_BYTES]);
+smk_exchange *smk_exchange_create(smk_ctx *ctx, int rank, int nranks, const unsigned char *id, int npix, int *err);
+int smk_exchange_connect_local(smk_exchange *const *all, int nranks);
+void smk_exchange_destroy(smk_exchange *x);
+const char *smk_exchange_last_error(smk_exchange *x); /* x may be NULL: last smk_exchange_create failure */
+void *smk_exchange_partial(smk_exchange *x, int slot);
+int smk_exchange_acquire(smk_exchange *x, int slot, void *render_stream);
+int smk_exchange_rendered(smk_exchange *x, int slot, void *render_stream);
+int smk_exchange_frame(smk_exchange *x, int slot, void *d_frame);
+int smk_exchange_frame_local(smk_exchange *const *all, int nranks, int slot, void *d_frame);
+int smk_exchange_wait(smk_exchange *x, void *stream);
 
 /* data prep on the GPU (genVGH/main.cpp:56-182, VectorMath.h:874-899,
  * 1133-1148, 1217-1281).  All pointers are DEVICE pointers.
@@ -188,7 +229,7 @@ int smk_get_raycoef(smk_ctx *ctx, smk_raycoef *out);
  *   "tf_raw"   [0] 1: the 2-D table handed to smk_set_tf2d is already opacity-corrected (copyScale off)
  *   "halo"     [1] voxels of halo kept around a shard's region (before smk_upload_volume)
  *   developer knobs: "tile" (slice-ring workgroup shape id), "slab_T" (band wait + 1), "slab_fly"
- *   (slices a loader keeps in flight), "lockstep" (bit 0 gather lockstep; bits 1..6 slice-ring
+ *   (slices a loader keeps in flight), "slab_ns" (cap on the ring's slots), "lockstep" (bit 0 gather lockstep; bits 1..6 slice-ring
  *   diagnostics, see tools/kbench.py), "wave_w"/"blk_w" (gather tile shape), "inject_slab_status"
  *   (test hook: the next slice-ring frame reports this status word) */
 int smk_set_option(smk_ctx *ctx, const char *key, int value);
@@ -200,7 +241,8 @@ int smk_timing_reset(smk_ctx *ctx);
 int smk_timing_read(smk_ctx *ctx, float *avg_ms, int *nframes);
 /* named counters of the last frame (developer statistics, no reference counterpart):
  * "slab_iters", "slab_active_lanes", "slab_inside_lanes", "slab_hit_lanes" (collected when option
- * lockstep has bit 16 set), "slab_status".  Synchronises the device. */
+ * lockstep has bit 16 set), "slab_status" (these synchronise the device); "slab_failures",
+ * "slab_retries" (host-side counters, no synchronisation). */
 int smk_get_stat(smk_ctx *ctx, const char *name, double *value);
 /* workgroup timeline of the last frame rendered with option lockstep bit 32 (developer tool):
  * records of 8 x uint32 {start, end (100 MHz ticks), HW_ID, XCC_ID | tile<<8 | slices<<20, loader 0's

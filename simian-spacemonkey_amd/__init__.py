@@ -5,5 +5,6 @@ thin ctypes front end used by the tests, bench.py and the multi-GPU driver.  The
 contains a hyphen, so load it with `importlib` (see tests/conftest.py::load_package) or through
 __graft_entry__.build().
 """
-from .binding import (SmkError, Renderer, build_library, library_path, load_library,  # noqa: F401
-                      ABI_SYMBOLS)
+from . import binding  # noqa: F401
+from .binding import (SmkError, Renderer, Exchange, exchange_unique_id, build_library, library_path,  # noqa: F401
+                      load_library, ABI_SYMBOLS)

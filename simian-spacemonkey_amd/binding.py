@@ -21,7 +21,10 @@ ABI_SYMBOLS = [
     "smk_set_perturb", "smk_set_blend", "smk_render", "smk_render_device", "smk_composite_over_device",
     "smk_make_vgh_device", "smk_normals_vgh_device", "smk_synth_volume_device",
     "smk_get_raycoef", "smk_set_option", "smk_last_frame_info", "smk_get_stat", "smk_get_trace", "smk_get_tf2d_effective",
-    "smk_timing_reset", "smk_timing_read",
+    "smk_timing_reset", "smk_timing_read", "smk_last_frame_id", "smk_frame_failed",
+    "smk_exchange_unique_id", "smk_exchange_create", "smk_exchange_connect_local", "smk_exchange_destroy",
+    "smk_exchange_last_error", "smk_exchange_partial", "smk_exchange_acquire", "smk_exchange_rendered", "smk_exchange_frame",
+    "smk_exchange_frame_local", "smk_exchange_wait",
 ]
 
 # gluvvDataMode order (gluvv.h:221-235)
@@ -118,6 +121,24 @@ def load_library():
     L.smk_get_stat.argtypes = [C.c_void_p, C.c_char_p, P(C.c_double)]
     L.smk_get_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int, P(C.c_int)]
     L.smk_get_tf2d_effective.argtypes = [C.c_void_p, C.c_void_p, P(C.c_float)]
+    L.smk_last_frame_id.argtypes = [C.c_void_p]
+    L.smk_last_frame_id.restype = C.c_longlong
+    L.smk_frame_failed.argtypes = [C.c_void_p, C.c_longlong]
+    L.smk_exchange_unique_id.argtypes = [C.c_void_p]
+    L.smk_exchange_create.restype = C.c_void_p
+    L.smk_exchange_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, P(C.c_int)]
+    L.smk_exchange_connect_local.argtypes = [P(C.c_void_p), C.c_int]
+    L.smk_exchange_destroy.argtypes = [C.c_void_p]
+    L.smk_exchange_destroy.restype = None
+    L.smk_exchange_last_error.restype = C.c_char_p
+    L.smk_exchange_last_error.argtypes = [C.c_void_p]
+    L.smk_exchange_partial.restype = C.c_void_p
+    L.smk_exchange_partial.argtypes = [C.c_void_p, C.c_int]
+    L.smk_exchange_acquire.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.smk_exchange_rendered.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.smk_exchange_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.smk_exchange_frame_local.argtypes = [P(C.c_void_p), C.c_int, C.c_int, C.c_void_p]
+    L.smk_exchange_wait.argtypes = [C.c_void_p, C.c_void_p]
     L.smk_timing_reset.argtypes = [C.c_void_p]
     L.smk_timing_read.argtypes = [C.c_void_p, P(C.c_float), P(C.c_int)]
     _LIB = L
@@ -298,6 +319,13 @@ class Renderer:
         self._ck(self.L.smk_composite_over_device(self.ctx, d_layers, nlayers,
                                                   (C.c_int * nlayers)(*order), npix, d_out, stream))
 
+    def last_frame_id(self):
+        return int(self.L.smk_last_frame_id(self.ctx))
+
+    def frame_failed(self, frame_id):
+        """after synchronising with that frame: True = the slice-ring kernel flagged it, render it again"""
+        return bool(self.L.smk_frame_failed(self.ctx, int(frame_id)))
+
     # -- introspection
     def raycoef(self):
         rc = RayCoef()
@@ -378,3 +406,59 @@ class Renderer:
     def synth_volume_device(self, kind, seed, dims, d_out):
         sx, sy, sz = dims
         self._ck(self.L.smk_synth_volume_device(self.ctx, kind, seed, sx, sy, sz, d_out))
+
+
+def exchange_unique_id():
+    """the 128-byte RCCL communicator id (rank 0 makes it, every other rank needs the same bytes)"""
+    buf = (C.c_ubyte * 128)()
+    if load_library().smk_exchange_unique_id(buf) != 0:
+        raise SmkError("smk_exchange_unique_id failed (librccl.so.1 not loadable?)")
+    return bytes(buf)
+
+
+class Exchange:
+    """One rank's end of the sort-last merge behind the C ABI (smk_exchange_*): direct send of tiles,
+    ordered over, gather.  id = the RCCL communicator id (one process per GPU) or None (all ranks are
+    contexts of this process: Exchange.connect_local + Exchange.frame_local)."""
+
+    def __init__(self, renderer, rank, nranks, npix, id=None):
+        self.L, self.r = renderer.L, renderer
+        err = C.c_int(0)
+        idbuf = (C.c_ubyte * 128).from_buffer_copy(id) if id is not None else None
+        self.x = self.L.smk_exchange_create(renderer.ctx, rank, nranks, idbuf, npix, C.byref(err))
+        if not self.x:
+            raise SmkError(self.L.smk_exchange_last_error(None).decode())
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise SmkError(self.L.smk_exchange_last_error(self.x).decode())
+
+    def close(self):
+        if self.x:
+            self.L.smk_exchange_destroy(self.x)
+            self.x = None
+
+    def partial(self, slot):
+        return self.L.smk_exchange_partial(self.x, slot)
+
+    def acquire(self, slot, render_stream=None):
+        self._ck(self.L.smk_exchange_acquire(self.x, slot, render_stream))
+
+    def rendered(self, slot, render_stream=None):
+        self._ck(self.L.smk_exchange_rendered(self.x, slot, render_stream))
+
+    def frame(self, slot, d_frame):
+        self._ck(self.L.smk_exchange_frame(self.x, slot, d_frame))
+
+    def wait(self, stream=None):
+        self._ck(self.L.smk_exchange_wait(self.x, stream))
+
+    @staticmethod
+    def connect_local(xs):
+        arr = (C.c_void_p * len(xs))(*[x.x for x in xs])
+        xs[0]._ck(xs[0].L.smk_exchange_connect_local(arr, len(xs)))
+
+    @staticmethod
+    def frame_local(xs, slot, d_frame):
+        arr = (C.c_void_p * len(xs))(*[x.x for x in xs])
+        xs[0]._ck(xs[0].L.smk_exchange_frame_local(arr, len(xs), slot, d_frame))

@@ -52,6 +52,12 @@ struct SmkCorner {
   uint32_t nb;
 };
 
+// native strip-major layout (smk_internal.h): stored voxel (x, y, z) -> element index
+__device__ __forceinline__ size_t smk_vox_index(const RenderParams &P, int x, int y, int z) {
+  const int L = P.sw_log2;
+  return ((((size_t)z * P.nsx + (size_t)(x >> L)) * P.D[1] + (size_t)y) << L) | (size_t)(x & ((1 << L) - 1));
+}
+
 template <int DT>
 __device__ __forceinline__ SmkCorner smk_load_corner(const RenderParams &P, size_t idx) {
   SmkCorner k;

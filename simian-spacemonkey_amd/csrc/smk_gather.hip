@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
 
   float C0 = 0.f, C1 = 0.f, C2 = 0.f, C3 = 0.f;
   float first = __int_as_float(0x7f800000);
-  const int Dx = P.D[0], Dy = P.D[1];
+  const int Dy = P.D[1];
 
   // blend order: front to back (and GL_MAX, which has no order) walk m upwards; back to front
   // (VolumeRenderer.cpp:590) starts at the far plane
@@ -115,12 +115,17 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
     y1 = min(max(y1 - P.O[1], 0), P.D[1] - 1);
     z0 = min(max(z0 - P.O[2], 0), P.D[2] - 1);
     z1 = min(max(z1 - P.O[2], 0), P.D[2] - 1);
-    size_t r00 = ((size_t)z0 * Dy + y0) * Dx, r10 = ((size_t)z0 * Dy + y1) * Dx;
-    size_t r01 = ((size_t)z1 * Dy + y0) * Dx, r11 = ((size_t)z1 * Dy + y1) * Dx;
-    SmkCorner k000 = smk_load_corner<DT>(P, r00 + x0), k100 = smk_load_corner<DT>(P, r00 + x1);
-    SmkCorner k010 = smk_load_corner<DT>(P, r10 + x0), k110 = smk_load_corner<DT>(P, r10 + x1);
-    SmkCorner k001 = smk_load_corner<DT>(P, r01 + x0), k101 = smk_load_corner<DT>(P, r01 + x1);
-    SmkCorner k011 = smk_load_corner<DT>(P, r11 + x0), k111 = smk_load_corner<DT>(P, r11 + x1);
+    // strip-major layout: element = ((z * nsx + x / SW) * Dy + y) * SW + x % SW; the two x columns
+    // differ by one element inside a strip, by a whole strip (Dy rows) across its edge
+    const int SL = P.sw_log2, SM = (1 << SL) - 1;
+    const size_t c0 = ((size_t)(x0 >> SL) * Dy << SL) + (size_t)(x0 & SM), c1 = ((size_t)(x1 >> SL) * Dy << SL) + (size_t)(x1 & SM);
+    const size_t zs = (size_t)P.nsx * Dy << SL;  // elements per z slice
+    size_t r00 = (size_t)z0 * zs + ((size_t)y0 << SL), r10 = (size_t)z0 * zs + ((size_t)y1 << SL);
+    size_t r01 = (size_t)z1 * zs + ((size_t)y0 << SL), r11 = (size_t)z1 * zs + ((size_t)y1 << SL);
+    SmkCorner k000 = smk_load_corner<DT>(P, r00 + c0), k100 = smk_load_corner<DT>(P, r00 + c1);
+    SmkCorner k010 = smk_load_corner<DT>(P, r10 + c0), k110 = smk_load_corner<DT>(P, r10 + c1);
+    SmkCorner k001 = smk_load_corner<DT>(P, r01 + c0), k101 = smk_load_corner<DT>(P, r01 + c1);
+    SmkCorner k011 = smk_load_corner<DT>(P, r11 + c0), k111 = smk_load_corner<DT>(P, r11 + c1);
 
     const float sc = DT == 0 ? SMK_INV255 : 1.0f;
     float ch0 = SMK_TRI(c0), ch1 = 0.f, ch2 = 0.f, ch3 = 0.f;

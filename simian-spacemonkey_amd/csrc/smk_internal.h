@@ -11,7 +11,18 @@
 #include "../../include/smk.h"
 
 #define SMK_MAX_RANKS 8
+// HBM layout of the packed volume: STRIP-major.  A strip row is SMK_STRIP_UNITS 16-byte units =
+// one 128-byte line (8 f32 voxels / 16 u8 voxels) along the layout's contiguous axis U; the rows of
+// a strip follow each other along V, strips along U, slices along S:
+//     unit address (u, v, s) = ((s * NSu + u / SW) * Dv + v) * SW + u % SW        (SW voxels per strip row)
+// so the (u,v) window a pixel tile needs of a slice is a few strips x a run of ADJACENT 128-byte
+// lines each -- measured with tools/dma_probe.hip ("strips"): LDS-DMA streams such windows at
+// 6.4-6.7 TB/s, the row-major [s][v][u] layout of round 1 (480-byte row pieces 16 KiB apart) at 4.85.
+#define SMK_STRIP_UNITS 8
+#define SMK_STRIP_LOG2_F32 3  // voxels per strip row, log2: 8 x 16 B
+#define SMK_STRIP_LOG2_U8 4   // 16 x 8 B
 #define SMK_TIMING_RING 64
+#define SMK_STATUS_RING 8  // frames whose slice-ring status stays readable (smk_frame_failed)
 
 // Everything a render kernel needs, passed by value as the kernarg (wave-uniform => SGPRs).
 struct RenderParams {
@@ -23,6 +34,8 @@ struct RenderParams {
   int N[3];             // whole-volume dims
   int O[3];             // global index of stored voxel (0,0,0)
   int D[3];             // stored dims (region + halo)
+  int sw_log2;          // log2(voxels per strip row): 3 (f32) or 4 (u8)
+  int nsx;              // strips along x in the native layout (S=z, U=x, V=y): ceil(D[0] / 2^sw_log2)
   float lo[3], hi[3];   // region in voxel coordinates: [g0-.5, g1-.5)
   int top[3];           // region touches the volume's top face on this axis (inclusive)
   int cplane_on;        // free clip plane: a sample stays when fma-chain(cplane . (p,1)) >= 0 (voxel coordinates)
@@ -65,7 +78,8 @@ struct RenderParams {
 
 // side buffers of the slice-ring kernel, owned by the context
 struct SlabAux {
-  int *h_status = nullptr;      // pinned, device-visible: error word (0 = ok)
+  int *h_status = nullptr;      // pinned, device-visible: SMK_STATUS_RING error words (0 = ok), one per frame in turn
+  int status_slot = 0;          // the word of the frame being launched
   hipEvent_t frame_ev0 = nullptr;  // recorded by the launcher right before its first stream operation
   float *d_diag = nullptr;      // [16] diagnostic counters (option lockstep bit 16)
   int *d_order = nullptr;       // tile schedule of the current camera
@@ -110,7 +124,9 @@ struct smk_ctx {
   int cplane_on = 0;  // free clip plane (glClipPlane), eye space
   double cplane_eye[4] = {0, 0, 0, 0};
   void *d_vox = nullptr;
-  void *d_vox_x = nullptr;  // x-major copy [x][z][y] for views whose principal axis is x (lazy)
+  // lazily built re-orderings for the slice-ring kernel, same strip-major scheme with other axes:
+  void *d_vox_x = nullptr;  // S = x, U = y, V = z (views whose principal axis is x)
+  void *d_vox_y = nullptr;  // S = y, U = x, V = z (principal axis y)
   std::string slab_why;     // why the last frame fell back to the gather kernel ("" if it did not)
   uint32_t *d_nrm = nullptr;
   bool have_normals = false;
@@ -161,13 +177,17 @@ struct smk_ctx {
   // options / stats
   int opt_kernel = 0, opt_slab_T = 0, opt_tf_raw = 0, opt_tile = 0;
   int opt_slab_fly = 0;  // slices a loader keeps in flight (0 = default)
+  int opt_slab_ns = 0;   // cap on the ring's slots (0 = as many as fit)
   int opt_inject_status = 0;  // (test hook) the next slice-ring frame reports this status word
   int opt_wave_w = 8, opt_blk_w = 2, opt_lockstep = 1;
   SlabAux slab;  // slice-ring kernel side buffers
   // auto mode (option kernel = 0) picks the ray-marcher by measurement: the first frames of a
   // new configuration run the slice-ring kernel, then the gather kernel (bit-identical frames),
   // and the faster one is kept for that configuration
-  std::map<unsigned long long, int> tune_choice;
+  long long frame_id = 0;                  // frames enqueued so far (smk_last_frame_id)
+  long long slab_failures = 0, slab_retries = 0;  // slice-ring frames flagged invalid / re-rendered by smk_render
+  struct TuneEntry { int kernel; long long expires; };  // (a measured or forced choice is re-examined after a while)
+  std::map<unsigned long long, TuneEntry> tune_choice;
   unsigned long long last_slab_sig = 0;  // configuration of the latest slice-ring launch (a failed one is not tried again)
   unsigned long long tune_sig = 0;
   int tune_state = 0, tune_slot[2] = {0, 0};
@@ -180,6 +200,6 @@ struct smk_ctx {
 hipError_t smk_launch_gather(const RenderParams &P, int dtype, int tf_mode, int shade_kind,
                              hipStream_t s);
 // returns hipErrorNotSupported (and *why) when the frame must use the gather kernel
+// vox_by_perm[0..2]: the layouts for S = z / y / x (null = not built yet: *why says which)
 hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T, int opt_tile, int forced,
-                           const void *vox_native, const void *vox_xmajor, SlabAux *aux, const char **why,
-                           hipStream_t s);
+                           const void *const vox_by_perm[3], SlabAux *aux, const char **why, hipStream_t s);

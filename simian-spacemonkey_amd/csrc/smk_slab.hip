@@ -40,14 +40,18 @@
 
 // wave-uniform description of one launch
 struct SlabParams {
-  int perm;                    // 0: S=z (U=x,V=y)  1: S=y (U=x,V=z)  2: S=x (U=y,V=z; x-major copy)
+  int perm;                    // 0: S=z (U=x,V=y; native)  1: S=y (U=x,V=z; y-major copy)  2: S=x (U=y,V=z; x-major copy)
   int au, av, as;              // model-axis index of U, V, S
-  long long strideV, strideS;  // voxel strides of the layout in use (U stride is 1)
+  // strip-major layout in use (smk_internal.h): a strip row = 128 B, the rows of a strip are adjacent
+  // along V, strips follow along U, slices along S
+  unsigned stripStrideB;       // bytes from one strip to the next = Dv * 128
+  long long strideSb;          // bytes from one slice to the next = NSu * Dv * 128
+  int DuPad;                   // stored U extent padded to whole strips (voxels)
   int Ou, Ov, Os;              // stored-box origin along U,V,S (global voxel index)
   int Du, Dv, Ds;              // stored-box dims along U,V,S
   int wu;                      // 16-byte units per window row that are loaded at most (<= wp)
   int wv;                      // window rows that are loaded
-  int wp;                      // LDS row pitch in 16-byte units, a multiple of 8: the slot image is flat with this
+  int wp;                      // LDS row pitch in 16-byte units, a multiple of 4 with wp / gcd(64, wp) <= 7: the slot image is flat with this
                                // pitch, so the (row, column) a DMA lane serves repeats every `per` chunks = `rpg` rows
   int per, rpg;                // chunks and rows per group: per = wp / gcd(64, wp), rpg = 64 / gcd(64, wp)
   int groups;                  // row groups per slice = ceil(wv / rpg); chunks = groups * per
@@ -224,12 +228,12 @@ __device__ __forceinline__ float slab_tex_chan(const SlabTexel4 &x, int k) {
 // (2 x 9 waves = 5 on one SIMD) if the kernel stays within 96 VGPRs
 template <int DT, int SH, int PERM, int NW, int NL, bool DIAG>
 __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) == 5 || (NW + NL) == 10) ? 5 : ((NW + NL) == 11 ? 3 : 4)) void smk_k_slab(const RenderParams P, const SlabParams Q) {
-  typedef typename VoxT<DT>::type Vox;
   constexpr int UPV = DT == 0 ? 2 : 1;   // voxels per 16-byte DMA unit
   constexpr int VB = DT == 0 ? 8 : 16;   // bytes per voxel
   // (global_load_lds_dwordx3 does NOT compact: it writes 12 bytes per lane at a 16-byte lane stride
   //  -- tools/dma_layout_probe.hip -- so staging only {c0,c1,c2} needs a 12-byte HBM plane)
   constexpr int VBL = DT == 0 ? 3 : 4;   // log2
+  constexpr int SWV = SMK_STRIP_UNITS * UPV;  // voxels per strip row
   constexpr int NTH = (NW + NL) * 64;
   // big workgroups (one per CU, 128 VGPRs each): read whole voxels, release ring slots early
   constexpr bool EARLY = (NW + NL) > 10;
@@ -424,9 +428,9 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       v0 = max(v0 - Q.Ov, 0);
       u1 = min(u1 - Q.Ou, Q.Du - 1);
       v1 = min(v1 - Q.Ov, Q.Dv - 1);
-      if (UPV == 2) u0 &= ~1;  // rows start on whole 16-byte units (the stored U extent is even)
-      // fixed-shape window: slide it back inside the stored box where it would stick out
-      const int wu0 = min(u0, Q.Du - wuv), wv0 = min(v0, Q.Dv - Q.wv);
+      u0 &= ~(SWV / 2 - 1);  // windows start on half strips (64 B)
+      // fixed-shape window: slide it back inside the stored box (padded to whole strips) where it would stick out
+      const int wu0 = min(u0, Q.DuPad - wuv), wv0 = min(v0, Q.Dv - Q.wv);
       if (u1 - wu0 + 1 > wuv || v1 - wv0 + 1 > Q.wv) ctl[3] = 2;  // host bound violated: reported, never silent
       // what this slice really needs of the fixed-shape window (the loader masks the rest)
       const int need_u = max((u1 - wu0 + UPV) / UPV, 1), need_v = max(v1 - wv0 + 1, 1);
@@ -469,18 +473,25 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       const int per = Q.per, rpg = Q.rpg, groups = Q.groups;
       const int mygroups = (groups - lid + NL - 1) / NL;
       const int mych = mygroups * per;  // DMA wave-instructions of a whole window (this loader's share)
-      const unsigned strideVb = (unsigned)(Q.strideV * (long long)sizeof(Vox));  // bytes, < 2^32
-      // unit 64*k + lane of a group sits at (row, column) = divmod(64*k + lane, wp): fixed per lane and phase k
-      unsigned voff[7], rowk[7], colk[7];
+      constexpr unsigned strideVb = SMK_STRIP_UNITS * 16u;  // a window row advances one 128-byte line inside every strip
+      // unit 64*k + lane of a group sits at (row, column) = divmod(64*k + lane, wp): fixed per lane and phase k;
+      // column c (units from the window's strip-aligned origin) lives in strip c / 8, unit c % 8 of that strip's row
+      // Windows start on HALF strips (64 B: alignment to whole strips costs a strip of LDS per row, and the
+      // ring's depth is what the frame time hangs on): two static offset sets, origin at a strip's first /
+      // fifth unit; a slice picks one by its origin's parity.  Inner strips are read as whole 128-byte lines
+      // either way, only the window's outer half strips as 64-byte pieces.
+      unsigned voffA[7], voffB[7], rowk[7], colk[7];
 #pragma unroll
       for (int k = 0; k < 7; ++k) {
         const unsigned g = 64u * k + lane;
         rowk[k] = g / (unsigned)Q.wp;
         colk[k] = g - rowk[k] * (unsigned)Q.wp;
-        voff[k] = rowk[k] * strideVb + colk[k] * 16u;
+        const unsigned cb = colk[k] + SMK_STRIP_UNITS / 2;
+        voffA[k] = rowk[k] * strideVb + (colk[k] / SMK_STRIP_UNITS) * Q.stripStrideB + (colk[k] % SMK_STRIP_UNITS) * 16u;
+        voffB[k] = rowk[k] * strideVb + (cb / SMK_STRIP_UNITS) * Q.stripStrideB + (cb % SMK_STRIP_UNITS) * 16u;
       }
       const size_t gstep = (size_t)(NL * rpg) * strideVb;  // source advance from one of my groups to the next
-      const size_t strideSb = (size_t)Q.strideS * sizeof(Vox);
+      const size_t strideSb = (size_t)Q.strideSb;
       const bool l2hot = DIAG && (P.lockstep & 8) != 0;           // (diagnostic: every slice re-reads one slice)
       int q = 0, inflight = 0, landed = 0, idle = 0, minp = 0, slot_q = 0, fly_total = 0;
       int fly_counts = 0;  // lane (q & 63): DMA wave-instructions of load index q (a scalar array in one VGPR)
@@ -503,9 +514,26 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
                : "=&s"(keep_m0)                                                                                     \
                : "v"(voff_), "s"(dst_), "s"(src_)                                                                   \
                : "memory")
-      // table entries of 64 consecutive load indices, one per lane, refreshed every 64 slices:
-      // a slice's window origin is then one v_readlane away instead of an LDS round trip
+      // table entries of 64 consecutive load indices, one per lane, refreshed every 64 slices: a
+      // slice's window origin is then one v_readlane away instead of an LDS round trip, and the 64-bit
+      // source offset of this loader's first group of that slice is computed there, 64 slices per
+      // instruction, instead of ~25 scalar instructions per slice
       int ent_uv = 0;
+      unsigned ent_lo = 0, ent_hi = 0;
+      // per-slice state that rarely changes from one slice to the next is kept across slices and redone
+      // only when its key moves: the offset set (the window origin's half-strip parity flips every ~10
+      // slices) and the column masks (what a slice needs of the window's width)
+      unsigned voff[7];
+      bool cm[7];
+      unsigned long long mk[7];  // the column masks as wave-uniform lane masks (EXEC values)
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        voff[k] = voffA[k];
+        cm[k] = false;
+        mk[k] = 0;
+      }
+      bool last_odd = false;
+      unsigned last_need_u = 0xffffffffu;
       const bool prof = DIAG && (P.lockstep & 48) != 0 && Q.diag != nullptr;  // (diagnostic: where a loader's cycles go)
       long long t_issue = 0, t_wait = 0, t_idle = 0, t_mark = 0;
       const long long t_start = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -527,21 +555,34 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             const int ql = q + lane;
             const int e = (dir > 0 ? smin + ql : smax + 1 - ql) - Q.Os;
             ent_uv = -1;
-            if (ql <= npos && e >= 0 && e < Q.Ds) ent_uv = (int)raw_lds_b64(&wtab[e]).y;  // (.pack; never -1: u0 < 2^11)
+            if (ql <= npos && e >= 0 && e < Q.Ds) {
+              ent_uv = (int)raw_lds_b64(&wtab[e]).y;  // (.pack; never -1: u0 < 2^11)
+              // (u0 is a whole number of half strips, see the table: the base is its strip, the parity picks the offsets)
+              const unsigned eu0 = (unsigned)ent_uv & 0x7ffu, ev0 = ((unsigned)ent_uv >> 11) & 0x7ffu;
+              const unsigned long long off = (l2hot ? 0ull : (unsigned long long)e * (unsigned long long)strideSb) +
+                                             (unsigned long long)(eu0 / (unsigned)SWV) * Q.stripStrideB +
+                                             (unsigned long long)(ev0 + (unsigned)(lid * rpg)) * strideVb;
+              ent_lo = (unsigned)off;
+              ent_hi = (unsigned)(off >> 32);
+            }
           }
           const int uv = __builtin_amdgcn_readlane(ent_uv, q & 63);
           int issued = 0;  // DMA wave-instructions of this slice (this loader's share)
           const unsigned dst0 = ring_addr + (unsigned)(slot_q * Q.slot_bytes + lid * per * 1024);
           if (uv != -1) {
-            const int sl = (dir > 0 ? smin + q : smax + 1 - q) - Q.Os;
-            const unsigned u0 = (unsigned)uv & 0x7ffu, v0 = ((unsigned)uv >> 11) & 0x7ffu;
             // (small windows: the whole shape -- the saving would not pay for the partial-group path)
             const unsigned need_u = Q.mask_need ? (((unsigned)uv >> 22) & 0x3fu) + 1u : (unsigned)Q.wu;
             const unsigned need_v = Q.mask_need ? (unsigned)Q.wv - ((unsigned)uv >> 28) * (unsigned)((Q.wv + 15) / 16) : (unsigned)Q.wv;
-            const char *src = gv + (l2hot ? (size_t)0 : (size_t)sl * strideSb) + ((size_t)v0 * strideVb + (size_t)u0 * VB) +  // (64-bit: v0 * strideVb passes 4 GiB when V is the slowest axis of a 1024^3 volume)
-                              (size_t)(lid * rpg) * strideVb;
+            const char *src = gv + (((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ent_hi, q & 63) << 32) |
+                                    (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ent_lo, q & 63));
+            const bool odd_half = ((unsigned)uv & (unsigned)(SWV / 2)) != 0;  // wave-uniform (bit of u0)
+            if (odd_half != last_odd) {
+              last_odd = odd_half;
+#pragma unroll
+              for (int k = 0; k < 7; ++k) voff[k] = odd_half ? voffB[k] : voffA[k];
+            }
             unsigned dst = dst0, row0 = (unsigned)(lid * rpg);
-            // per = wp / gcd(64, wp) is 1, 3, 5 or 7 for a pitch that is a multiple of 8 units
+            // per = wp / gcd(64, wp) is 1, 3, 5 or 7 (the host picks such a pitch)
 #define SLAB_GROUP(CHUNK)              \
   CHUNK(0)                             \
   if (per >= 3) {                      \
@@ -557,12 +598,13 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             // only the group the needed rows end in pays a per-lane row test (lane 0 always loads
             // there, so that a group is `per` wave-instructions: the in-order vmcnt counts slices
             // through the per-slice instruction counts kept in fly_counts).
-            bool cm[7];
-            unsigned long long mk[7];  // the same column masks as wave-uniform lane masks (EXEC values)
+            if (need_u != last_need_u) {
+              last_need_u = need_u;
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-              cm[k] = k < per && colk[k] < need_u;
-              mk[k] = __builtin_amdgcn_ballot_w64(cm[k]);
+              for (int k = 0; k < 7; ++k) {
+                cm[k] = k < per && colk[k] < need_u;
+                mk[k] = __builtin_amdgcn_ballot_w64(cm[k]);
+              }
             }
             for (int g = 0; g < mygroups; ++g) {
               if (FIFO) {
@@ -609,7 +651,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             // slice outside the stored box (never read): uniform counting wants its instructions all the same
             unsigned dst = dst0;
             for (int c = 0; c < mych; ++c) {
-              SLAB_DMA(gv, dst, voff[0] * 0u);
+              SLAB_DMA(gv, dst, voffA[0] * 0u);
               dst += 1024u;
             }
           }
@@ -1107,9 +1149,9 @@ static hipError_t launch_slab(const RenderParams &P, const SlabParams &Q, size_t
 
 // plan + launch; returns hipErrorNotSupported when the configuration must use the gather kernel
 hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T, int opt_tile, int forced,
-                           const void *vox_native, const void *vox_xmajor, SlabAux *aux, const char **why,
-                           hipStream_t s) {
-  const int opt_fly = (opt_T >> 8) & 0xff;  // (developer knobs travel packed: slab_T | slab_fly << 8)
+                           const void *const vox_by_perm[3], SlabAux *aux, const char **why, hipStream_t s) {
+  const int opt_fly = (opt_T >> 8) & 0xff;  // (developer knobs travel packed: slab_T | slab_fly << 8 | slab_ns << 16)
+  const int opt_ns = (opt_T >> 16) & 0xff;
   opt_T &= 0xff;
   *why = nullptr;
   if (P.pert_on) { *why = "perturbation"; return hipErrorNotSupported; }
@@ -1127,27 +1169,29 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     if (fabs(Bc[a]) > fabs(Bc[as])) as = a;
   SlabParams Q;
   memset(&Q, 0, sizeof Q);
-  Q.status = aux->h_status;
+  Q.status = aux->h_status + aux->status_slot;
   Q.diag = aux->d_diag;
   Q.as = as;
   if (as == 2) { Q.perm = 0; Q.au = 0; Q.av = 1; }
   else if (as == 1) { Q.perm = 1; Q.au = 0; Q.av = 2; }
   else { Q.perm = 2; Q.au = 1; Q.av = 2; }
-  if (Q.perm == 2 && !vox_xmajor) { *why = "x-major copy unavailable"; return hipErrorNotSupported; }
+  if (Q.perm == 2 && !vox_by_perm[2]) { *why = "x-major copy unavailable"; return hipErrorNotSupported; }
+  if (Q.perm == 1 && !vox_by_perm[1]) { *why = "y-major copy unavailable"; return hipErrorNotSupported; }
   Q.dir = Bc[as] > 0 ? 1 : -1;
   Q.Ou = P.O[Q.au]; Q.Ov = P.O[Q.av]; Q.Os = P.O[as];
   Q.Du = P.D[Q.au]; Q.Dv = P.D[Q.av]; Q.Ds = P.D[as];
-  if (Q.perm == 0) { Q.strideV = P.D[0]; Q.strideS = (long long)P.D[0] * P.D[1]; Q.vox = vox_native; }
-  else if (Q.perm == 1) { Q.strideV = (long long)P.D[0] * P.D[1]; Q.strideS = P.D[0]; Q.vox = vox_native; }
-  else { Q.strideV = P.D[1]; Q.strideS = (long long)P.D[1] * P.D[2]; Q.vox = vox_xmajor; }  // [x][z][y]
+  const int swv = 1 << P.sw_log2;  // voxels per strip row
+  const int nsu = (Q.Du + swv - 1) / swv;
+  Q.DuPad = nsu * swv;
+  Q.stripStrideB = (unsigned)Q.Dv * 128u;
+  Q.strideSb = (long long)nsu * Q.Dv * 128;
+  Q.vox = vox_by_perm[Q.perm];
   if (P.cplane_on) { *why = "free clip plane (a per-sample half-space test: gather kernel)"; return hipErrorNotSupported; }
   // an empty region (a clip plane outside a shard's box): the gather kernel's explicit comparisons
   // render it as nothing; the median-of-three membership test here needs lo <= hi
   for (int a = 0; a < 3; ++a)
     if (!(P.lo[a] <= P.hin[a])) { *why = "region is empty"; return hipErrorNotSupported; }
   if (Q.Ds > 4096) { *why = "more than 4096 slices"; return hipErrorNotSupported; }
-  // u8 voxels are 8 B: the DMA moves 16-B units, so rows must start and end on even voxels
-  if (dtype == 0 && ((Q.Du & 1) || (Q.strideV & 1) || (Q.strideS & 1))) { *why = "odd U extent for 8-byte voxels"; return hipErrorNotSupported; }
 
   // workgroup shape: consumer waves are 8x8 pixel sub-tiles; NL loader waves.
   //   light windows: 32x16 tile, 8+1 waves, two workgroups per CU
@@ -1235,8 +1279,16 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     const double span = P.N[as] <= 3 ? 3.0 : 2.5;
     int Wu = (int)ceil(max_eu + span * max_drift_u + 2 * SLAB_EPS) + 2;
     int Wv = (int)ceil(max_ev + span * max_drift_v + 2 * SLAB_EPS) + 2;
-    if (dtype == 0) Wu = ((Wu + 1) & ~1) + 2;  // even width, even alignment of the origin
-    Wu = std::min(Wu, Q.Du);
+    // windows start on half strips (4 units): up to hsw - 1 voxels of slack in front, whole half strips in all
+    const int hsw = swv / 2;
+    Wu = (Wu + (hsw - 1) + (hsw - 1)) / hsw * hsw;
+    // the flat image's pitch must repeat the lane pattern within 7 chunks: wp / gcd(64, wp) <= 7
+    for (;; Wu += hsw) {
+      int g = 64, r = Wu / upv;
+      while (r) { int t = g % r; g = r; r = t; }
+      if ((Wu / upv) / g <= 7) break;
+    }
+    Wu = std::min(Wu, Q.DuPad);
     Wv = std::min(Wv, Q.Dv);
     if (Wu < 2 || Wv < 2) { *why = "degenerate window"; return hipErrorNotSupported; }
     // fixed window shape: wu 16-byte units per row on an LDS pitch of the next multiple of 8 units
@@ -1246,7 +1298,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     Q.wv = Wv;
     if (Q.wu > 64) { if (ci + 1 < ncfg) continue; *why = "window wider than one DMA chunk"; return hipErrorNotSupported; }
     if (Q.Du > 2047 || Q.Dv > 2047) { *why = "stored box wider than 2047 voxels across the view"; return hipErrorNotSupported; }
-    Q.wp = (Q.wu + 7) & ~7;
+    Q.wp = Q.wu;  // a multiple of 4 units with wp / gcd(64, wp) <= 7 (or the whole padded stored extent)
     {
       int g = 64, r = Q.wp;
       while (r) { int t = g % r; g = r; r = t; }  // gcd(64, wp)
@@ -1286,6 +1338,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
       ns = (int)((158 * 1024 - fixed) / (size_t)Q.slot_bytes);
       if (ns > band + 4) ns = band + 4;
     }
+    if (opt_ns >= 3 && ns > opt_ns) ns = opt_ns;  // (experiment knob: cap the ring)
     if (ns < 3) { if (ci + 1 < ncfg) continue; *why = "window does not fit LDS"; return hipErrorNotSupported; }
     Q.nslots = ns;
     const int mych = (Q.groups + nl - 1) / nl * Q.per;  // most DMA instructions one loader issues per slice

@@ -77,14 +77,24 @@ def exchange_and_composite(partial, order, compositor, group=None, recv=None, vi
     return compositor(layers, order)
 
 
-def gather_frame(tile, dst=0, group=None, via_host=False):
-    """finished tiles -> full frame on rank dst ([npix_padded,4]); None elsewhere"""
+def gather_frame(tile, dst=0, group=None, via_host=False, into=None):
+    """finished tiles -> full frame on rank dst ([npix_padded,4]); None elsewhere.  `into` (rank dst):
+    a preallocated [P, tile, 4] buffer the tiles are received into (no allocation per frame)."""
     P = dist.get_world_size(group)
     me = dist.get_rank(group)
     src = tile.cpu() if via_host and tile.is_cuda else tile
-    out = [torch.empty_like(src) for _ in range(P)] if me == dst else None
+    out = None
+    if me == dst:
+        if into is not None and not (via_host and tile.is_cuda):
+            out = list(into.unbind(0))
+        else:
+            out = [torch.empty_like(src) for _ in range(P)]
     dist.gather(src, out, dst=dst, group=group)
-    return torch.cat(out, 0).to(tile.device) if me == dst else None
+    if me != dst:
+        return None
+    if into is not None and not (via_host and tile.is_cuda):
+        return into.view(-1, 4)
+    return torch.cat(out, 0).to(tile.device)
 
 
 class Pipeline:
@@ -95,9 +105,15 @@ class Pipeline:
     shard into the [npix_padded,4] buffer at `ptr`; `compositor(layers, order, out, stream_handle)`
     merges [P, tile, 4] front to back into `out`."""
 
-    def __init__(self, render, compositor, npix, group=None, slots=2, via_host=False):
+    def __init__(self, render, compositor, npix, group=None, slots=2, via_host=False, frame_check=None):
+        """frame_check(token, ptr, stream_handle) -> bool (token = what render() returned), called once a frame's ray-marcher has finished and
+        BEFORE its layer is exchanged: True = the frame was invalid and has been rendered again into
+        the same buffer (the product passes Renderer.frame_failed + a gather-kernel re-render).  The
+        repair is local to the rank, so no rank ever leaves the others waiting in a collective."""
         self.render, self.compositor, self.group, self.via_host = render, compositor, group, via_host
+        self.frame_check = frame_check
         P = dist.get_world_size(group)
+        me = dist.get_rank(group)
         tp = tile_pixels(npix, P)
         self.npix = npix
         self.slots = []
@@ -106,13 +122,20 @@ class Pipeline:
                 "stream": torch.cuda.Stream(),
                 "partial": torch.zeros((tp * P, 4), dtype=torch.float32, device="cuda"),
                 "recv": torch.empty((tp * P, 4), dtype=torch.float32, device="cuda"),
-                "tile": torch.zeros((tp, 4), dtype=torch.float32, device="cuda")})
+                "tile": torch.zeros((tp, 4), dtype=torch.float32, device="cuda"),
+                # rank 0: where the finished tiles of a frame are gathered (allocated once)
+                "full": torch.empty((P, tp, 4), dtype=torch.float32, device="cuda") if me == 0 else None})
         self.count = 0
+        self.repaired = 0        # frames frame_check had to render again
         self.marched = None      # event: the latest frame's ray-marcher has finished
         self.delivered = None    # event: the latest frame has been copied into the caller's buffer
+        self.pending = None      # the frame whose layer has not been exchanged yet
 
     def frame(self, out, order):
-        """enqueue one frame; on rank 0 `out` ([npix,4]) receives it.  Returns at once."""
+        """enqueue one frame; on rank 0 `out` ([npix,4]) receives it.  Returns at once.  The frame's
+        layer is exchanged when the NEXT frame has been enqueued (or at drain()): its ray-marcher has
+        then had a frame's time to run, so looking at its status costs the host no wait to speak of,
+        and the exchange still overlaps the next frame's ray-marching."""
         sl = self.slots[self.count % len(self.slots)]
         self.count += 1
         s = sl["stream"]
@@ -120,23 +143,79 @@ class Pipeline:
         with torch.cuda.stream(s):
             if self.marched is not None:
                 s.wait_event(self.marched)
-            self.render(sl["partial"].data_ptr(), s.cuda_stream)
+            sl["token"] = self.render(sl["partial"].data_ptr(), s.cuda_stream)   # (whatever identifies the frame to frame_check)
             self.marched = torch.cuda.Event()
             self.marched.record(s)
+        sl["marched"], sl["out"], sl["order"] = self.marched, out, order
+        prev, self.pending = self.pending, sl
+        if prev is not None:
+            self._exchange(prev)
+
+    def _exchange(self, sl):
+        s = sl["stream"]
+        with torch.cuda.stream(s):
+            if self.frame_check is not None:
+                sl["marched"].synchronize()
+                if self.frame_check(sl["token"], sl["partial"].data_ptr(), s.cuda_stream):
+                    self.repaired += 1
 
             def comp(layers, order_):
                 self.compositor(layers, order_, sl["tile"], s.cuda_stream)
                 return sl["tile"]
-            tile = exchange_and_composite(sl["partial"], order, comp, self.group, sl["recv"], self.via_host)
-            full = gather_frame(tile, 0, self.group, self.via_host)
+            tile = exchange_and_composite(sl["partial"], sl["order"], comp, self.group, sl["recv"], self.via_host)
+            full = gather_frame(tile, 0, self.group, self.via_host, into=sl["full"])
             if full is not None:
                 if self.delivered is not None:
                     s.wait_event(self.delivered)
-                out.copy_(full[:self.npix])
+                sl["out"].copy_(full[:self.npix])
                 self.delivered = torch.cuda.Event()
                 self.delivered.record(s)
 
     def drain(self):
-        """make the caller's current stream wait for every frame enqueued so far"""
+        """exchange the last frame and make the caller's current stream wait for every frame enqueued so far"""
+        if self.pending is not None:
+            self._exchange(self.pending)
+            self.pending = None
         for sl in self.slots:
             torch.cuda.current_stream().wait_stream(sl["stream"])
+
+
+class ExchangePipeline:
+    """Pipeline's contract with the merge behind the C ABI (smk_exchange_*, RCCL transport: grouped
+    ncclSend/ncclRecv direct send, ordered over, gather -- csrc/smk_exchange.hip).  Python only
+    sequences the calls; no torch collective is in the data path."""
+
+    def __init__(self, render, exchange, npix, rank, frame_check=None):
+        self.render, self.x, self.npix, self.rank, self.frame_check = render, exchange, npix, rank, frame_check
+        self.count = 0
+        self.repaired = 0
+        self.pending = None
+
+    def frame(self, out, order=None):
+        slot = self.count & 1
+        self.count += 1
+        st = torch.cuda.current_stream().cuda_stream
+        self.x.acquire(slot, st)
+        token = self.render(self.x.partial(slot), st)
+        self.x.rendered(slot, st)
+        ev = torch.cuda.Event()
+        ev.record()
+        prev, self.pending = self.pending, (slot, token, ev, out)
+        if prev is not None:
+            self._exchange(prev)
+
+    def _exchange(self, p):
+        slot, token, ev, out = p
+        if self.frame_check is not None:
+            ev.synchronize()
+            st = torch.cuda.current_stream().cuda_stream
+            if self.frame_check(token, self.x.partial(slot), st):
+                self.repaired += 1
+                self.x.rendered(slot, st)
+        self.x.frame(slot, out.data_ptr() if self.rank == 0 else None)
+
+    def drain(self):
+        if self.pending is not None:
+            self._exchange(self.pending)
+            self.pending = None
+        self.x.wait(torch.cuda.current_stream().cuda_stream)

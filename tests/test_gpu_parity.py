@@ -147,3 +147,42 @@ def test_cfg5_multi_field_dense_tf_and_perturbation(gpu_renderer_factory, O, wor
         assert np.abs(img - ref).max() <= 1e-4
     finally:
         R.close()
+
+
+@pytest.mark.parametrize("kind,f32,shade", [("cfg1", False, 0), ("cfg3", True, 1)])
+def test_blend_orders_and_mip(gpu_renderer_factory, O, kind, f32, shade):
+    """The reference's three framebuffer blends: front to back (R8kVolRen3D.cpp:1441-1449, the
+    product's default), back to front (VolumeRenderer.cpp:590 -- the scalar path's actual order,
+    NV20VolRen3D.cpp:930) and GL_MAX (gluvvShadeMIP, NV20VolRen3D.cpp:158-163).  Each against the CPU
+    checker's own implementation of that blend (1e-4); and the two 'over' orders against each other: they
+    are the same operator evaluated from opposite ends, equal up to fp32 rounding (stated: 2e-6)."""
+    sc = make_scene(kind, n=32, size=56, steps=64, pose="rot", f32=f32, shade=shade)
+    R = gpu_renderer_factory()
+    try:
+        push_scene(R, sc)
+        R.set_option("kernel", 0)
+        frames = {}
+        for name, mode in (("ftb", 0), ("btf", 1), ("max", 2)):
+            R.set_blend(name)
+            img, dep = R.render(depth=True)
+            ref, rdep = sc.render(blend=mode, depth=True)
+            assert ref[..., 3].max() > 0.05
+            assert np.abs(img - ref).max() <= 1e-4, name
+            hit = np.isfinite(rdep)
+            assert np.array_equal(np.isfinite(dep), hit) and np.abs(dep[hit] - rdep[hit]).max() <= 1e-4, name
+            frames[name] = img
+        assert np.abs(frames["ftb"] - frames["btf"]).max() <= 2e-6
+        assert np.abs(frames["ftb"] - sc.render(blend=1)).max() <= 2e-6     # FTB frame vs the checker's back-to-front one
+        assert (frames["max"][..., 3] <= frames["ftb"][..., 3] + 1e-6).all()  # the largest sample alpha never exceeds the accumulated one
+        if kind == "cfg3":   # GL_MAX on the slice-ring kernel: bit-identical to the gather kernel's
+            R.set_blend("max")
+            R.set_option("kernel", 1)
+            a = R.render()
+            R.set_option("kernel", 2)
+            b = R.render()
+            assert R.last_frame_info()[0] == 2 and np.array_equal(a, b)
+            R.set_blend("btf")
+            with pytest.raises(Exception, match="back-to-front"):
+                R.render()
+    finally:
+        R.close()

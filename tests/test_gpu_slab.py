@@ -322,3 +322,61 @@ def test_a_failed_slice_ring_frame_is_rendered_again_and_not_tried_twice(gpu_ren
         assert np.abs(out.cpu().numpy().reshape(64, 64, 4) - sc.render()).max() <= TOL
     finally:
         r.close()
+
+
+def test_frames_in_flight_report_their_own_status(gpu_renderer_factory):
+    """smk_render_device only enqueues; each frame has its own status word.  A caller that keeps frames in
+    flight asks about a frame after synchronising with it (smk_frame_failed), renders a flagged one again
+    and goes on: no later call fails, and the counters a benchmark asserts on show what happened."""
+    import torch
+    r = gpu_renderer_factory()
+    try:
+        sc = make_scene("cfg3", n=32, size=64, steps=64, pose="rot", f32=True, shade=1)
+        ref = sc.render()
+        push_scene(r, sc)
+        r.set_option("kernel", 2)
+        out = torch.zeros((2, 64 * 64, 4), dtype=torch.float32, device="cuda")
+        r.render_device(out[0].data_ptr(), None, None)
+        a = r.last_frame_id()
+        r.set_option("inject_slab_status", 1)
+        r.render_device(out[1].data_ptr(), None, None)        # a second frame behind the first, flagged
+        b = r.last_frame_id()
+        assert b == a + 1
+        torch.cuda.synchronize()
+        assert r.stat("slab_failures") == 1                   # seen without being consumed
+        assert not r.frame_failed(a) and r.frame_failed(b)
+        assert not r.frame_failed(b)                          # asked and answered
+        r.set_option("kernel", 1)
+        r.render_device(out[1].data_ptr(), None, None)        # the repair: no error from the earlier frame
+        torch.cuda.synchronize()
+        assert np.abs(out[1].cpu().numpy().reshape(64, 64, 4) - ref).max() <= TOL
+        assert r.stat("slab_failures") == 1 and r.stat("slab_retries") == 0
+    finally:
+        r.close()
+
+
+def test_a_pose_the_slice_ring_kernel_declines_does_not_pin_later_frames(gpu_renderer_factory):
+    """Auto mode plans every frame afresh: a wide-angle close-up (rays up to ~74 degrees off the principal
+    axis: 'too oblique') runs on the gather kernel, and the very next ordinary frame is back on the
+    slice-ring kernel -- a declined pose is not remembered against the configuration."""
+    r = gpu_renderer_factory()
+    try:
+        sc = make_scene("cfg3", n=32, size=64, steps=64, pose="rot", f32=True, shade=1)
+        push_scene(r, sc)
+        r.set_option("kernel", 0)
+        for _ in range(6):
+            r.render()
+        assert r.last_frame_info()[0] == 2
+        wide = make_scene("cfg3", n=32, size=64, steps=64, pose="rot", f32=True, shade=1)
+        wide.eye, wide.frustum = (0, 0, -1.1), (-3.5, 3.5, -3.5, 3.5)
+        push_scene(r, wide, upload=False)
+        img = r.render()
+        assert r.last_frame_info()[0] == 1
+        assert np.abs(img - wide.render()).max() <= TOL
+        push_scene(r, sc, upload=False)
+        for _ in range(6):                                    # (at most: the two kernels are timed again)
+            img = r.render()
+        assert r.last_frame_info()[0] == 2
+        assert np.abs(img - sc.render()).max() <= TOL
+    finally:
+        r.close()
