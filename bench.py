@@ -109,11 +109,14 @@ def modelview(xform, fsize):
 
 # --------------------------------------------------------------------------- workload set-up
 
-def make_volume(r, n, seed=1):
-    """synthetic scalar -> f32 VGH + u8 normals, all on the GPU (smk_prep.hip); returns tensors"""
+def make_volume(r, n, seed=1, kind=1):
+    """synthetic scalar -> f32 VGH + u8 normals, all on the GPU (smk_prep.hip); returns tensors.
+    kind 1: the reference's own test volume, genvol spheres (`-spheres 4 -p 10 -pscale .7 -pwrap 3 3 3
+    -pabs -blur -bw 1 1 1 .7`, srand(seed)), generated on the GPU byte for byte as the CPU
+    checker's Perlin-pinned restatement does (tests/test_gpu_prep.py); kind 0: round 1's smooth shells."""
     dims = (n, n, n)
     scalar = torch.empty((n, n, n), dtype=torch.uint8, device="cuda")
-    r.synth_volume_device(0, seed, dims, scalar.data_ptr())
+    r.synth_volume_device(kind, seed, dims, scalar.data_ptr())
     vgh8 = torch.empty((n, n, n, 3), dtype=torch.uint8, device="cuda")
     vghf = torch.empty((n, n, n, 3), dtype=torch.float32, device="cuda")
     r.make_vgh_device(scalar.data_ptr(), 0, dims, 1, vgh8.data_ptr(), vghf.data_ptr())
@@ -176,6 +179,133 @@ def timed(r, K, W, frame, world, cstate, settle=True):
         t = float(tt.item())
     kms, kn = r.timing_read()
     return t, kms, kn
+
+
+def roofline(r, kms, alg_bytes, size, note=None, traffic=None):
+    """HBM roofline object of the ray-march kernel: algorithmic bytes per launch (every stored voxel once + TF
+    + the 16-byte RGBA frame, smk_last_frame_info) over the kernel's HIP-event time.  The slice-ring
+    kernel's loaders stop streaming a tile once all its rays are saturated: the voxel bytes are scaled by
+    the share of the tiles' slices that was really streamed (counted in-kernel), so an opaque transfer
+    function cannot inflate the fraction."""
+    frame_bytes = 16.0 * size * size
+    streamed = float(r.stat("slab_streamed_fraction"))
+    net = (alg_bytes - frame_bytes) * streamed + frame_bytes
+    ach = net / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+           "frac_of_achievable_6300": ach / 6300.0,   # float4-copy ceiling measured on MI355X (MI355X_MICROARCH.md, HBM)
+           "traffic": traffic, "kernel_ms": kms,
+           "algorithmic_bytes_per_launch": net, "algorithmic_bytes_if_every_slice_streamed": alg_bytes,
+           "slices_streamed_fraction": streamed}
+    if note:
+        out["note"] = note
+    return out
+
+
+def libc_noise_tex(n=32):
+    """R8kVolRen3D_cpy::createNoiseTex (:2392-2436): n^3 RGBA8 from libc's srand(1)/rand(), as the adapter makes it"""
+    import ctypes
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(1)
+    v = np.array([libc.rand() for _ in range(n * n * n * 4)], dtype=np.float64)
+    t = (v.astype(np.float32) / np.float32(2147483647)).astype(np.float64) * .5 + .5 + 1.0 / 512
+    return (t * 255).astype(np.int32).astype(np.uint8).reshape(n, n, n, 4)
+
+
+def north_star_parity(vghf_h, nrm_h, tf_eff, size, planes, xform, mv, gpu_frame, nrays=200):
+    """max |GPU - CPU checker| over `nrays` random rays of the north-star frame (the checker marches per ray)"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    sc = O.Scene(vghf_h, grad=nrm_h)
+    sc.tf_mode, sc.tf_vg = 1, tf_eff
+    sc.tf_h, sc.third_axis = np.load(os.path.join(ROOT, "tests", "golden", "tf_h_slider05.npy")), 1
+    sc.width = sc.height = size
+    sc.steps = planes
+    sc.xform = [float(v) for v in xform.T.reshape(-1)]
+    sc.mv_override = mv
+    sc.shade_mode, sc.use_spec = 1, 1
+    sc.frustum = FRUSTUM
+    pix = np.random.default_rng(11).integers(size // 8, size - size // 8, size=(nrays, 2)).astype(np.int32)
+    ref = sc.render_pixels(pix)
+    return float(np.abs(gpu_frame[pix[:, 1], pix[:, 0]] - ref).max())
+
+
+def extra_legs(r, frame, work, steps):
+    """Secondary timings on the same JSON line (N=1): transfer functions that are NOT kind to the kernel,
+    and BASELINE config 5.  Each: K frames after a settle, HIP-event kernel time, net roofline."""
+    g = os.path.join(ROOT, "tests", "golden")
+    out = {}
+    K = max(3, min(steps, 8))
+
+    def run(name, size, planes, describe):
+        fr = frame[:size * size]
+        with torch.cuda.stream(work):
+            t, kms, kn = timed(r, K, 1, fr, 1, None)
+        kernel, _, alg = r.last_frame_info()
+        out[name] = {"workload": describe, "ms_per_frame": t / K * 1e3, "Msamples_per_s": float(size) * size * planes / (t / K) / 1e6,
+                     "kernel": {1: "gather", 2: "slab-staged"}.get(kernel, str(kernel)),
+                     "roofline": roofline(r, kms, alg, size)}
+
+    # cfg2: 256^3 u8 VGH, the reference's default deptex ramp (NV20VolRen3D.cpp:1479-1486), 512^2 x 256, no shading
+    n = 256
+    scalar = torch.empty((n, n, n), dtype=torch.uint8, device="cuda")
+    r.synth_volume_device(1, 1, (n, n, n), scalar.data_ptr())
+    vgh8 = torch.empty((n, n, n, 3), dtype=torch.uint8, device="cuda")
+    r.make_vgh_device(scalar.data_ptr(), 0, (n, n, n), 1, vgh8.data_ptr(), None)
+    r.upload_volume_device(vgh8.data_ptr(), (n, n, n), 3, 0, None)
+    del scalar
+    xform = rotation((1, 1, 0), 30)
+    xf = [float(v) for v in xform.T.reshape(-1)]
+    r.set_tf2d(np.load(os.path.join(g, "tf_cfg2_deptex.npy")), None)
+    r.set_camera(modelview(xform, (1.0, 1.0, 1.0)), FRUSTUM, (1.0, 20.0), 512, 512)
+    r.set_sampling(0.0, 256, 1.0, 1)
+    r.set_shading("none", LIGHT, EYE, AT, xf, INTENS)
+    r.set_perturb(None, None, None)
+    run("cfg2_default_ramp", 512, 256, "cfg2: 256^3 u8 VGH (genvol spheres), the reference's default (value, gradient) ramp table, "
+        "512x512x256, unshaded: a DENSE transfer function (every sample classified and blended)")
+    del vgh8
+    # an opaque table on the headline volume: rays saturate within a few samples, the loaders stop early
+    n = 512
+    vghf, nrm = make_volume(r, n)
+    r.upload_volume_device(vghf.data_ptr(), (n, n, n), 3, 1, nrm.data_ptr())
+    del vghf, nrm
+    torch.cuda.empty_cache()
+    configure(r, "cfg3", n, 1024, 512)
+    opaque = np.load(os.path.join(g, "tf_cfg3_levwidget.npy")).copy()
+    opaque[..., 3] = 255
+    opaque[..., :3] = np.maximum(opaque[..., :3], 64)
+    r.set_tf2d(opaque, None)
+    run("opaque_tf", 1024, 512, "cfg3's volume and camera with an OPAQUE table (alpha 255 everywhere): the bytes counted are those of "
+        "the slices really streamed")
+    # BASELINE config 5 on one GPU: two 512^3 fields merged on the GPU (mergeMV + addG), dense 3-D table,
+    # noise-perturbed fetch (createNoiseTex's texture, gluvvui's default weights (.2, 0) would displace by 51
+    # voxels: SURVEY 8d's (.2, .1) scaled to the volume, see DESIGN), 1024^2 x 1024
+    fields = torch.empty((n, n, n, 2), dtype=torch.uint8, device="cuda")
+    one = torch.empty((n, n, n), dtype=torch.uint8, device="cuda")
+    for e, seed in enumerate((1, 2)):
+        r.synth_volume_device(1, seed, (n, n, n), one.data_ptr())
+        fields[..., e] = one
+    del one
+    merged = torch.empty((n, n, n, 3), dtype=torch.uint8, device="cuda")
+    mnrm = torch.empty((n, n, n, 3), dtype=torch.uint8, device="cuda")
+    r.merge_fields_device(fields.data_ptr(), 2, (n, n, n), merged.data_ptr(), mnrm.data_ptr())
+    del fields
+    r.upload_volume_device(merged.data_ptr(), (n, n, n), 3, 0, mnrm.data_ptr(), dmode="V2G")
+    del merged, mnrm
+    torch.cuda.empty_cache()
+    rng = np.random.default_rng(5)
+    t3 = rng.integers(0, 256, (16, 16, 16, 4), dtype=np.uint8)
+    t3[..., 3] = (t3[..., 3].astype(np.float32) * 0.25).astype(np.uint8)
+    r.set_option("tf_raw", 1)
+    r.set_tf3d(t3)
+    r.set_camera(modelview(xform, (1.0, 1.0, 1.0)), FRUSTUM, (1.0, 20.0), 1024, 1024)
+    r.set_sampling(0.0, 1024, 1.0, 1)
+    r.set_shading("r8k", LIGHT, EYE, AT, xf, INTENS)
+    run("cfg5_unperturbed", 1024, 1024, "cfg5 without the perturbation: 2 x 512^3 u8 fields merged (V2G), dense 3-D table, R8k Phong, 1024x1024x1024")
+    r.set_perturb(libc_noise_tex(32), (.02, .01, 0, 0), (.2, 2.1, 4.5, 8.7))
+    run("cfg5", 1024, 1024, "cfg5: the same with the noise-perturbed fetch (32^3 noise, weights .02/.01, scales .2/2.1): gather kernel")
+    r.set_perturb(None, None, None)
+    r.set_option("tf_raw", 0)
+    return out
 
 
 def cpu_baseline(vghf, nrm, tf_path, size, planes, xform, mv, gpu_frame, budget_s=12.0):
@@ -252,6 +382,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 gather, 2 slab-staged")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-north-star", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary timings (dense / opaque tables, config 5)")
     ap.add_argument("--north-star-volume", type=int, default=1024)
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -368,14 +499,11 @@ def main():
                    "kernel": {1: "gather", 2: "slab-staged"}.get(kernel, str(kernel))},
     }
     if rank == 0:
-        ach = alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBPS,
-                           "traffic": pmc_traffic("cfg3") if default_workload and world == 1 else None,
-                           "kernel_ms": kms, "kernel_frames_timed": kn,
-                           "algorithmic_bytes_per_launch": alg_bytes,
-                           "note": "this rank's shard; %d^3 f32 working set is VALU/LDS-bound by "
-                                   "construction (BASELINE.md sec. 2), see north_star" % n}
+        out["roofline"] = roofline(r, kms, alg_bytes, size,
+                                   note="this rank's shard; %d^3 f32 working set is VALU/LDS-bound by construction "
+                                        "(BASELINE.md sec. 2), see north_star" % n,
+                                   traffic=pmc_traffic("cfg3") if default_workload and world == 1 else None)
+        out["roofline"]["kernel_frames_timed"] = kn
     failures = int(r.stat("slab_failures"))
     if world > 1:
         out["rccl_ranks"] = 0 if rehearse else world
@@ -413,26 +541,33 @@ def main():
         nn_ = a.north_star_volume
         v2, g2 = make_volume(r, nn_)
         r.upload_volume_device(v2.data_ptr(), (nn_, nn_, nn_), 3, 1, g2.data_ptr())
+        v2h = g2h = None
+        if not a.no_cpu:       # host copies for the checker (13 + 3 GB), before the device tensors go
+            v2h, g2h = v2.cpu().numpy(), g2.cpu().numpy()
         del v2, g2
         torch.cuda.empty_cache()
-        configure(r, "cfg4", nn_, size, planes)
+        xform, mv2 = configure(r, "cfg4", nn_, size, planes)
         k2 = max(3, min(a.steps, 10))
         with torch.cuda.stream(work):
             t2, kms2, kn2 = timed(r, k2, 2, frame, 1, None)
         kernel2, _, alg2 = r.last_frame_info()
-        ach2 = alg2 / (kms2 * 1e-3) / 1e9 if kms2 > 0 else 0.0
+        rl2 = roofline(r, kms2, alg2, size, traffic=pmc_traffic("north_star") if default_workload and nn_ == 1024 else None)
+        # SURVEY 8(d) counts the f32 VGH triple alone (12 B/voxel); the algorithmic bytes above add the 3
+        # normal bytes per voxel the Phong term reads
+        rl2["frac_on_vgh_bytes_only"] = rl2["frac"] * (12.0 / 15.0)
         out["north_star"] = {
             "workload": "cfg4 single GPU: %d^3 f32 VGH + u8 normals, (v,g)x(h) TF, R8k Phong, %dx%dx%d" % (nn_, size, size, planes),
             "ms_per_frame": t2 / k2 * 1e3, "fps": k2 / t2, "Msamples_per_s": samples / (t2 / k2) / 1e6,
-            "roofline": {"bound": "hbm", "achieved": ach2, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": ach2 / HBM_PEAK_GBPS,
-                         "traffic": pmc_traffic("north_star") if default_workload and nn_ == 1024 else None,
-                         "kernel_ms": kms2,
-                         "algorithmic_bytes_per_launch": alg2,
-                         # SURVEY 8(d) counts the f32 VGH triple alone (12 B/voxel); alg2 adds the 3
-                         # normal bytes per voxel the Phong term reads
-                         "frac_on_vgh_bytes_only": (alg2 - 3.0 * nn_ ** 3) / (kms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS if kms2 > 0 else 0.0},
-            "kernel": {1: "gather", 2: "slab-staged"}.get(kernel2, str(kernel2))}
+            "roofline": rl2, "kernel": {1: "gather", 2: "slab-staged"}.get(kernel2, str(kernel2))}
+        if not a.no_cpu:
+            # parity of the north-star frame itself: the CPU checker on 200 random rays of it
+            torch.cuda.synchronize()
+            ns_frame = frame.view(size, size, 4).cpu().numpy()
+            tf_eff2, _ = r.tf2d_effective(256, 256)
+            out["north_star"]["parity_max_abs_err"] = north_star_parity(v2h, g2h, tf_eff2, size, planes, xform, mv2, ns_frame)
+        del v2h, g2h
+        if not a.no_extra:
+            out["extra"] = extra_legs(r, frame, work, a.steps)
     bad = out["slab_failures"] != 0 or r.stat("slab_retries") != 0
     if rank == 0:
         print(json.dumps(out))

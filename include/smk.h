@@ -170,8 +170,9 @@ int smk_composite_over_device(smk_ctx *ctx, const void *d_layers, int nlayers, c
  * render_stream); smk_exchange_frame enqueues that frame's merge on the exchange's own stream behind
  * that mark and returns at once, so frame i's merge overlaps frame i+1's ray-marching (which may
  * already be enqueued: a host checks smk_frame_failed for frame i in between).  d_frame ([npix][4], rank 0 only) receives the merged frame;
- * smk_exchange_wait makes a stream wait for everything enqueued so far.  The context must have been
- * sharded with the same rank / nranks (smk_set_shard). */
+ * smk_exchange_wait makes a stream wait for everything enqueued so far.  A NULL stream means the
+ * context's own stream, as in smk_render_device.  The context must have been sharded with the same
+ * rank / nranks (smk_set_shard). */
 typedef struct smk_exchange smk_exchange;
 #define SMK_EXCHANGE_ID_BYTES 128
 int smk_exchange_unique_id(unsigned char id[SMK_EXCHANGE_ID_BYTES]);
@@ -209,8 +210,11 @@ int smk_merge_fields_device(smk_ctx *ctx, const void *d_fields_u8, int nf, int s
  * [z][y][x][nelts] is already in device memory. */
 int smk_hist2d(smk_ctx *ctx, const smk_volume_desc *bricks, int n_bricks, int nelts, unsigned char *hist);
 int smk_hist2d_device(smk_ctx *ctx, const void *d_vol_u8, int nelts, int sx, int sy, int sz, unsigned char *hist);
-/* synthetic scalar test volume generated on the GPU (bench input; analytic, seed-stable):
- * kind 0 = noisy concentric shells (u8) */
+/* synthetic scalar test volumes generated on the GPU (u8, [z][y][x]):
+ *   kind 1 = the reference's own generator: `genvol -spheres 4 -p 10 -pscale .7 -pwrap 3 3 3 -pabs -blur
+ *            -bw 1 1 1 .7` with srand(seed) (genvol/main.cpp:153-165, 212-256, 334-430; perlin.c; script
+ *            genvol/scripts/make64.bat:1) -- bytes identical to a CPU run of that tool on glibc
+ *   kind 0 = smooth noisy concentric shells (analytic, no staircase; round-1 bench input) */
 int smk_synth_volume_device(smk_ctx *ctx, int kind, unsigned seed, int sx, int sy, int sz,
                             void *d_scalar_u8);
 

@@ -79,6 +79,20 @@ def load_library():
         raise SmkError("libsmk_hip.so is not built (run __graft_entry__.build()); "
                        "there is no CPU fallback")
     L = C.CDLL(so)
+    if os.environ.get("SMK_LIB"):
+        # developer override (an older or experimental build beside the product library): entry points
+        # it lacks become stubs that fail when called, so the prototypes below can still be set
+        class _Missing:
+            def __init__(self, name):
+                self.name = name
+
+            def __call__(self, *a):
+                raise SmkError("%s is not in %s" % (self.name, so))
+        for name in ABI_SYMBOLS:
+            try:
+                getattr(L, name)
+            except AttributeError:
+                setattr(L, name, _Missing(name))
     P = C.POINTER
     L.smk_create.restype = C.c_void_p
     L.smk_create.argtypes = [C.c_int, P(C.c_int)]

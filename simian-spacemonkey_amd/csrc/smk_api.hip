@@ -66,9 +66,7 @@ static void free_volume(smk_ctx *c) {
   if (c->d_vox) (void)hipFree(c->d_vox);
   if (c->d_nrm) (void)hipFree(c->d_nrm);
   if (c->d_vox_x) (void)hipFree(c->d_vox_x);
-  if (c->d_vox_y) (void)hipFree(c->d_vox_y);
   c->d_vox_x = nullptr;
-  c->d_vox_y = nullptr;
   c->d_vox = nullptr;
   c->d_nrm = nullptr;
   c->have_volume = false;
@@ -104,12 +102,11 @@ extern "C" const char *smk_last_error(smk_ctx *c) { return c ? c->err.c_str() : 
 // ------------------------------------------------------------------------------- volume upload
 
 // source voxel (brick-local, caller layout [z][y][x][nelts] + optional [z][y][x][3] normals)
-// -> packed voxel in the dense region+halo box, strip-major (smk_internal.h).  One thread per
-// source voxel of the chunk.
+// -> packed voxel in the dense region+halo box.  One thread per source voxel of the chunk.
 template <int DT>
 __global__ void smk_k_pack(const void *src, const unsigned char *grad, int bx, int by, int cz, int nelts,
                            int gx0, int gy0, int gz0,  // global index of the chunk's first voxel
-                           int Ox, int Oy, int Oz, int Dx, int Dy, int Dz, int nsx, void *dst, uint32_t *nrm, int n_in_w) {
+                           int Ox, int Oy, int Oz, int Dx, int Dy, int Dz, void *dst, uint32_t *nrm, int n_in_w) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t total = (size_t)bx * by * cz;
   if (t >= total) return;
@@ -118,8 +115,7 @@ __global__ void smk_k_pack(const void *src, const unsigned char *grad, int bx, i
   int z = (int)(t / ((size_t)bx * by));
   int X = gx0 + x - Ox, Y = gy0 + y - Oy, Z = gz0 + z - Oz;
   if (X < 0 || X >= Dx || Y < 0 || Y >= Dy || Z < 0 || Z >= Dz) return;
-  constexpr int SL = DT == 0 ? SMK_STRIP_LOG2_U8 : SMK_STRIP_LOG2_F32;
-  size_t o = ((((size_t)Z * nsx + (size_t)(X >> SL)) * Dy + (size_t)Y) << SL) | (size_t)(X & ((1 << SL) - 1));
+  size_t o = ((size_t)Z * Dy + Y) * Dx + X;
   uint32_t nb = 0x00808080u;
   if (grad) nb = (uint32_t)grad[t * 3] | ((uint32_t)grad[t * 3 + 1] << 8) | ((uint32_t)grad[t * 3 + 2] << 16);
   if (DT == 0) {
@@ -202,14 +198,22 @@ static int upload_impl(smk_ctx *c, const smk_volume_desc *b, int nb, int nelts, 
     c->O[a] = lo;
     c->D[a] = hi - lo;
   }
-  // strip-major layout: x is padded up to whole strips (pad columns read as zero; no clamped texel
-  // pair reaches them, LDS-DMA windows may)
-  const int sl2 = dtype == SMK_U8 ? SMK_STRIP_LOG2_U8 : SMK_STRIP_LOG2_F32;
-  const int nsx = (c->D[0] + (1 << sl2) - 1) >> sl2;
-  size_t nst = ((size_t)c->D[2] * nsx * c->D[1]) << sl2;
+  // 8-byte voxels travel to LDS in 16-byte units: the slice-ring kernel wants even row lengths
+  // along both axes that can be its contiguous one (x, and y in the x-major copy) -- one more halo
+  // voxel where the volume has one, else a pad column nobody samples (index N: the texel pair of a
+  // clamped coordinate ends at N-1)
+  bool padded = false;
+  if (dtype == SMK_U8)
+    for (int a = 0; a < 2; ++a)
+      if (c->D[a] & 1) {
+        if (c->O[a] + c->D[a] < N[a]) ++c->D[a];
+        else if (c->O[a] > 0) { --c->O[a]; ++c->D[a]; }
+        else { ++c->D[a]; padded = true; }
+      }
+  size_t nst = (size_t)c->D[0] * c->D[1] * c->D[2];
   size_t vb = dtype == SMK_U8 ? 8 : 16;
-  HIPCHK(c, hipMalloc(&c->d_vox, nst * vb));
-  if ((nsx << sl2) != c->D[0]) HIPCHK(c, hipMemset(c->d_vox, 0, nst * vb));
+  HIPCHK(c, hipMalloc(&c->d_vox, nst * vb + 16));  // (+16: the gather kernel reads u8 voxels in pairs, smk_load_pair_u8)
+  if (padded) HIPCHK(c, hipMemset(c->d_vox, 0, nst * vb));
   c->vox_bytes = nst * vb;
   bool n_in_w = dtype == SMK_F32 && nelts <= 3;
   if (dtype == SMK_F32 && nelts == 4 && any_grad) HIPCHK(c, hipMalloc((void **)&c->d_nrm, nst * 4));
@@ -253,11 +257,11 @@ static int upload_impl(smk_ctx *c, const smk_volume_desc *b, int nb, int nelts, 
       unsigned blocks = (unsigned)((total + 255) / 256);
       if (dtype == SMK_U8)
         hipLaunchKernelGGL(smk_k_pack<0>, dim3(blocks), dim3(256), 0, 0, src, gsrc, k.xiSize, k.yiSize, cz, nelts,
-                           k.xiPos, k.yiPos, k.ziPos + z0, c->O[0], c->O[1], c->O[2], c->D[0], c->D[1], c->D[2], nsx,
+                           k.xiPos, k.yiPos, k.ziPos + z0, c->O[0], c->O[1], c->O[2], c->D[0], c->D[1], c->D[2],
                            c->d_vox, c->d_nrm, 0);
       else
         hipLaunchKernelGGL(smk_k_pack<1>, dim3(blocks), dim3(256), 0, 0, src, gsrc, k.xiSize, k.yiSize, cz, nelts,
-                           k.xiPos, k.yiPos, k.ziPos + z0, c->O[0], c->O[1], c->O[2], c->D[0], c->D[1], c->D[2], nsx,
+                           k.xiPos, k.yiPos, k.ziPos + z0, c->O[0], c->O[1], c->O[2], c->D[0], c->D[1], c->D[2],
                            c->d_vox, c->d_nrm, n_in_w ? 1 : 0);
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipDeviceSynchronize());
@@ -775,6 +779,24 @@ extern "C" int smk_get_stat(smk_ctx *c, const char *name, double *value) {
     *value = (double)n;
     return 0;
   }
+  // share of the slices in the tiles' ranges that the loaders of the latest slice-ring frame really
+  // streamed (they stop when every ray of a tile is saturated); synchronises
+  if (!strcmp(name, "slab_streamed_fraction")) {
+    *value = 1.0;
+    const int nt = c->slab.ticks_n_last;
+    if (c->last_kernel == 2 && c->slab.d_ticks && nt > 0) {
+      HIPCHK(c, hipDeviceSynchronize());
+      std::vector<unsigned> h((size_t)2 * nt);
+      HIPCHK(c, hipMemcpy(h.data(), c->slab.d_ticks + nt, (size_t)2 * nt * 4, hipMemcpyDeviceToHost));
+      double st = 0, pl = 0;
+      for (int t = 0; t < nt; ++t) {
+        st += h[t];
+        pl += h[(size_t)nt + t];
+      }
+      if (pl > 0) *value = st / pl;
+    }
+    return 0;
+  }
   if (!strcmp(name, "slab_retries")) {
     *value = (double)c->slab_retries;
     return 0;
@@ -811,8 +833,6 @@ static int build_params(smk_ctx *c, RenderParams &P) {
   if (refresh_tf2d(c, P.rc)) return 1;
   P.vox = c->d_vox;
   P.nrm = c->d_nrm;
-  P.sw_log2 = c->dtype == SMK_U8 ? SMK_STRIP_LOG2_U8 : SMK_STRIP_LOG2_F32;
-  P.nsx = (c->D[0] + (1 << P.sw_log2) - 1) >> P.sw_log2;
   for (int a = 0; a < 3; ++a) {
     P.N[a] = c->N[a];
     P.O[a] = c->O[a];
@@ -901,53 +921,35 @@ static int build_params(smk_ctx *c, RenderParams &P) {
   return 0;
 }
 
-// Re-orderings of the native layout (S=z, U=x, V=y) for views along the other two axes, so that the
-// slice-ring kernel always streams strip-major windows (288 GB of HBM buy the copies; one layout is
-// read per frame):  PERM 1: S=y, U=x, V=z      PERM 2: S=x, U=y, V=z.
-// A workgroup moves one strip column of 8/16 x-values x 32 y-values of one z: the read is one
-// contiguous run; PERM 1 writes whole strip rows (128 B) per y; PERM 2 turns the tile through LDS and
-// writes, per x, the 128-byte rows of the y-strips it covers.
-template <class V, int PERM>
-__global__ __launch_bounds__(256) void smk_k_relayout(const V *src, V *dst, int Dx, int Dy, int Dz, int nsx, int nsu) {
-  constexpr int SL = sizeof(V) == 8 ? SMK_STRIP_LOG2_U8 : SMK_STRIP_LOG2_F32, SW = 1 << SL;
-  constexpr int YB = 512 / SW;  // y rows per workgroup pass (u8: 32, f32: 64 -> two passes of 256 threads)
-  __shared__ V tile[YB][SW + 1];
-  const int z = blockIdx.z, xs = blockIdx.x, y0 = blockIdx.y * YB;
-  for (int t = threadIdx.x; t < YB * SW; t += 256) {
-    const int xl = t & (SW - 1), yl = t >> SL, y = y0 + yl;
-    if (y < Dy) tile[yl][xl] = src[((((size_t)z * nsx + xs) * Dy + y) << SL) | xl];
+// [z][y][x] -> [x][z][y] so that views along x also read contiguous rows (288 GB of HBM buys a
+// second layout; only one copy is read per frame).  32x32 tiles through LDS keep both sides
+// coalesced in 16-byte (f32: 2 x 8-byte) units.
+template <class V>
+__global__ __launch_bounds__(256) void smk_k_xmajor(const V *src, V *dst, int Dx, int Dy, int Dz) {
+  __shared__ V tile[32][33];
+  int z = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    int x = x0 + tx, y = y0 + r;
+    if (x < Dx && y < Dy) tile[r][tx] = src[((size_t)z * Dy + y) * Dx + x];
   }
   __syncthreads();
-  if (PERM == 1) {  // dst (u=x, v=z, s=y): ((y * nsx + xs) * Dz + z) * SW + xl
-    for (int t = threadIdx.x; t < YB * SW; t += 256) {
-      const int xl = t & (SW - 1), yl = t >> SL, y = y0 + yl;
-      if (y < Dy) dst[((((size_t)y * nsu + xs) * Dz + z) << SL) | xl] = tile[yl][xl];
-    }
-  } else {          // dst (u=y, v=z, s=x): ((x * nsy + y / SW) * Dz + z) * SW + y % SW
-    for (int t = threadIdx.x; t < YB * SW; t += 256) {
-      const int yl = t % YB, xl = t / YB, x = (xs << SL) + xl, y = y0 + yl;
-      if (x < Dx && y < Dy) dst[((((size_t)x * nsu + (y >> SL)) * Dz + z) << SL) | (y & (SW - 1))] = tile[yl][xl];
-    }
+  for (int r = ty; r < 32; r += 8) {
+    int x = x0 + r, y = y0 + tx;
+    if (x < Dx && y < Dy) dst[((size_t)x * Dz + z) * Dy + y] = tile[tx][r];
   }
 }
 
-static int make_relayout_copy(smk_ctx *c, int perm) {
-  void **slot = perm == 1 ? &c->d_vox_y : &c->d_vox_x;
-  if (*slot) return 0;
-  const int sl2 = c->dtype == SMK_U8 ? SMK_STRIP_LOG2_U8 : SMK_STRIP_LOG2_F32, sw = 1 << sl2;
-  const int nsx = (c->D[0] + sw - 1) >> sl2;
-  const int du = perm == 1 ? c->D[0] : c->D[1], ds = perm == 1 ? c->D[1] : c->D[0];
-  const int nsu = (du + sw - 1) >> sl2;
-  const size_t vb = c->dtype == SMK_U8 ? 8 : 16;
-  const size_t bytes = (((size_t)ds * nsu * c->D[2]) << sl2) * vb;
-  HIPCHK(c, hipMalloc(slot, bytes));
-  if ((nsu << sl2) != du) HIPCHK(c, hipMemsetAsync(*slot, 0, bytes, c->stream));
-  const int yb = 512 / sw;
-  dim3 grid(nsx, (c->D[1] + yb - 1) / yb, c->D[2]);
-#define RL(V, P_) hipLaunchKernelGGL((smk_k_relayout<V, P_>), grid, dim3(256), 0, c->stream, (const V *)c->d_vox, (V *)*slot, c->D[0], c->D[1], c->D[2], nsx, nsu)
-  if (c->dtype == SMK_U8) { if (perm == 1) RL(uint2, 1); else RL(uint2, 2); }
-  else { if (perm == 1) RL(float4, 1); else RL(float4, 2); }
-#undef RL
+static int make_xmajor_copy(smk_ctx *c) {
+  if (c->d_vox_x) return 0;
+  HIPCHK(c, hipMalloc(&c->d_vox_x, c->vox_bytes));
+  dim3 grid((c->D[0] + 31) / 32, (c->D[1] + 31) / 32, c->D[2]);
+  if (c->dtype == SMK_U8)
+    hipLaunchKernelGGL(smk_k_xmajor<uint2>, grid, dim3(256), 0, c->stream, (const uint2 *)c->d_vox, (uint2 *)c->d_vox_x,
+                       c->D[0], c->D[1], c->D[2]);
+  else
+    hipLaunchKernelGGL(smk_k_xmajor<float4>, grid, dim3(256), 0, c->stream, (const float4 *)c->d_vox,
+                       (float4 *)c->d_vox_x, c->D[0], c->D[1], c->D[2]);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
@@ -999,10 +1001,10 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
   c->slab.status_slot = (int)(c->frame_id % SMK_STATUS_RING);
   if (c->slab.h_status) ((volatile int *)c->slab.h_status)[c->slab.status_slot] = 0;
   // ---- auto mode: which kernel for this configuration?
-  bool try_slab = c->opt_kernel != 1 && c->tf_mode == 1;
+  bool try_slab = c->opt_kernel != 1 && (c->tf_mode == 1 || c->tf_mode == 2);
   unsigned long long sig = 0;
   int trial = -1;  // 0 / 1: this frame is the slice-ring / gather trial of a new configuration
-  if (c->opt_kernel == 0 && c->tf_mode == 1) {
+  if (c->opt_kernel == 0 && (c->tf_mode == 1 || c->tf_mode == 2)) {
     int as = 0;
     for (int a = 1; a < 3; ++a)
       if (fabsf(P.rc.Bc[a]) > fabsf(P.rc.Bc[as])) as = a;
@@ -1011,7 +1013,8 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
                                     (unsigned long long)c->H, (unsigned long long)P.rc.nplanes, (unsigned long long)shade_kind_of(c),
                                     (unsigned long long)P.third_axis, (unsigned long long)(as * 2 + (P.rc.Bc[as] > 0)),
                                     (unsigned long long)c->sv, (unsigned long long)c->sg, (unsigned long long)(d_depth != nullptr),
-                                    (unsigned long long)P.pert_on};
+                                    (unsigned long long)P.pert_on, (unsigned long long)c->tf_mode, (unsigned long long)c->s3v,
+                                    (unsigned long long)c->s3g, (unsigned long long)c->s3h, (unsigned long long)c->blend};
     sig = 1469598103934665603ull;
     for (unsigned long long v : f) sig = (sig ^ v) * 1099511628211ull;
     auto it = c->tune_choice.find(sig);
@@ -1052,14 +1055,11 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
     const char *why = nullptr;
     const int forced = c->opt_kernel == 2;
     c->slab.frame_ev0 = c->ev0;
-    const void *layouts[3] = {c->d_vox, c->d_vox_y, c->d_vox_x};
-    hipError_t e = smk_launch_slab(P, c->dtype, shade_kind_of(c), c->opt_slab_T | (c->opt_slab_fly << 8) | (c->opt_slab_ns << 16), c->opt_tile, forced, layouts,
-                                   &c->slab, &why, s);
-    if (e == hipErrorNotSupported && why && (!strcmp(why, "x-major copy unavailable") || !strcmp(why, "y-major copy unavailable"))) {
-      if (make_relayout_copy(c, !strcmp(why, "y-major copy unavailable") ? 1 : 2)) return 1;
-      layouts[1] = c->d_vox_y;
-      layouts[2] = c->d_vox_x;
-      e = smk_launch_slab(P, c->dtype, shade_kind_of(c), c->opt_slab_T | (c->opt_slab_fly << 8) | (c->opt_slab_ns << 16), c->opt_tile, forced, layouts, &c->slab, &why, s);
+    const int knobs = c->opt_slab_T | (c->opt_slab_fly << 8) | (c->opt_slab_ns << 16);
+    hipError_t e = smk_launch_slab(P, c->dtype, c->tf_mode, shade_kind_of(c), knobs, c->opt_tile, forced, c->d_vox, c->d_vox_x, &c->slab, &why, s);
+    if (e == hipErrorNotSupported && why && !strcmp(why, "x-major copy unavailable")) {
+      if (make_xmajor_copy(c)) return 1;
+      e = smk_launch_slab(P, c->dtype, c->tf_mode, shade_kind_of(c), knobs, c->opt_tile, forced, c->d_vox, c->d_vox_x, &c->slab, &why, s);
     }
     if (e == hipSuccess) {
       c->last_kernel = 2;

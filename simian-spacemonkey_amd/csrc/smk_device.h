@@ -16,6 +16,7 @@
 #include "smk_internal.h"
 
 #define SMK_INV255 (1.0f / 255.0f)
+#define SMK_RANGE_EPS 0.0078125f  // voxels; 30 x the fp32 rounding of coordinates up to 4096 (half an ulp = 2.4e-4)
 
 __device__ __forceinline__ float smk_lerp(float a, float b, float f) { return __fmaf_rn(f, b - a, a); }
 // clamp as ONE v_med3_f32 (fminf/fmaxf make hipcc add a canonicalising v_max first); for the
@@ -52,12 +53,6 @@ struct SmkCorner {
   uint32_t nb;
 };
 
-// native strip-major layout (smk_internal.h): stored voxel (x, y, z) -> element index
-__device__ __forceinline__ size_t smk_vox_index(const RenderParams &P, int x, int y, int z) {
-  const int L = P.sw_log2;
-  return ((((size_t)z * P.nsx + (size_t)(x >> L)) * P.D[1] + (size_t)y) << L) | (size_t)(x & ((1 << L) - 1));
-}
-
 template <int DT>
 __device__ __forceinline__ SmkCorner smk_load_corner(const RenderParams &P, size_t idx) {
   SmkCorner k;
@@ -82,6 +77,21 @@ __device__ __forceinline__ SmkCorner smk_load_corner(const RenderParams &P, size
     }
   }
   return k;
+}
+
+// u8 voxels are 8 bytes: the two x-neighbours of a sample sit side by side in memory and come with ONE
+// 16-byte load (a lane whose pair is not adjacent -- a clamped perturbed fetch -- loads the second one
+// separately).  Measured on BASELINE config 5: no change (16.8 ms either way): that frame is bound by
+// the latency of three dependent gathers per sample, not by their count.
+__device__ __forceinline__ void smk_load_pair_u8(const RenderParams &P, size_t i0, size_t i1, SmkCorner &a, SmkCorner &b) {
+  uint4 v;
+  __builtin_memcpy(&v, reinterpret_cast<const char *>(P.vox) + i0 * 8, 16);  // 8-byte aligned: one global_load_dwordx4
+  a.c0 = smk_ub(v.x, 0); a.c1 = smk_ub(v.x, 1); a.c2 = smk_ub(v.x, 2); a.c3 = smk_ub(v.x, 3);
+  a.nb = v.y;
+  uint2 w = make_uint2(v.z, v.w);
+  if (i1 != i0 + 1) w = ((const uint2 *)P.vox)[i1];
+  b.c0 = smk_ub(w.x, 0); b.c1 = smk_ub(w.x, 1); b.c2 = smk_ub(w.x, 2); b.c3 = smk_ub(w.x, 3);
+  b.nb = w.y;
 }
 
 #define SMK_TRI(field)                                                                  \
@@ -119,14 +129,22 @@ __device__ __forceinline__ float4 smk_tex3d(const uint32_t *tex, int ss, int st,
   smk_lin_clamp(__fmaf_rn(t, (float)st, -0.5f), st, t0, t1, ft);
   smk_lin_clamp(__fmaf_rn(r, (float)sr, -0.5f), sr, r0, r1, fr);
   uint32_t q[8];
-  q[0] = tex[(r0 * st + t0) * ss + s0];
-  q[1] = tex[(r0 * st + t0) * ss + s1];
-  q[2] = tex[(r0 * st + t1) * ss + s0];
-  q[3] = tex[(r0 * st + t1) * ss + s1];
-  q[4] = tex[(r1 * st + t0) * ss + s0];
-  q[5] = tex[(r1 * st + t0) * ss + s1];
-  q[6] = tex[(r1 * st + t1) * ss + s0];
-  q[7] = tex[(r1 * st + t1) * ss + s1];
+  if (ss >= 2) {  // the clamped texel pair is (s0, s0 + 1): four 8-byte gathers instead of eight 4-byte ones
+    uint2 p;
+    __builtin_memcpy(&p, tex + (r0 * st + t0) * ss + s0, 8); q[0] = p.x; q[1] = p.y;
+    __builtin_memcpy(&p, tex + (r0 * st + t1) * ss + s0, 8); q[2] = p.x; q[3] = p.y;
+    __builtin_memcpy(&p, tex + (r1 * st + t0) * ss + s0, 8); q[4] = p.x; q[5] = p.y;
+    __builtin_memcpy(&p, tex + (r1 * st + t1) * ss + s0, 8); q[6] = p.x; q[7] = p.y;
+  } else {
+    q[0] = tex[(r0 * st + t0) * ss + s0];
+    q[1] = tex[(r0 * st + t0) * ss + s1];
+    q[2] = tex[(r0 * st + t1) * ss + s0];
+    q[3] = tex[(r0 * st + t1) * ss + s1];
+    q[4] = tex[(r1 * st + t0) * ss + s0];
+    q[5] = tex[(r1 * st + t0) * ss + s1];
+    q[6] = tex[(r1 * st + t1) * ss + s0];
+    q[7] = tex[(r1 * st + t1) * ss + s1];
+  }
   float o[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e)

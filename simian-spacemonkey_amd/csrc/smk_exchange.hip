@@ -234,7 +234,7 @@ extern "C" int smk_exchange_acquire(smk_exchange *x, int slot, void *render_stre
   if (!x || slot < 0 || slot > 1) return 1;
   if (!x->used[slot]) return 0;
   XHIP(x, hipSetDevice(x->ctx->device));
-  XHIP(x, hipStreamWaitEvent((hipStream_t)render_stream, x->ev_sent[slot], 0));
+  XHIP(x, hipStreamWaitEvent(render_stream ? (hipStream_t)render_stream : x->ctx->stream, x->ev_sent[slot], 0));
   return 0;
 }
 
@@ -243,7 +243,8 @@ extern "C" int smk_exchange_acquire(smk_exchange *x, int slot, void *render_stre
 extern "C" int smk_exchange_rendered(smk_exchange *x, int slot, void *render_stream) {
   if (!x || slot < 0 || slot > 1) return 1;
   XHIP(x, hipSetDevice(x->ctx->device));
-  XHIP(x, hipEventRecord(x->ev_in[slot], (hipStream_t)render_stream));
+  // (NULL = the context's own stream, as in smk_render_device)
+  XHIP(x, hipEventRecord(x->ev_in[slot], render_stream ? (hipStream_t)render_stream : x->ctx->stream));
   return 0;
 }
 
@@ -353,7 +354,7 @@ extern "C" int smk_exchange_wait(smk_exchange *x, void *stream) {
   hipEvent_t ev;
   XHIP(x, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   hipError_t e = hipEventRecord(ev, x->xs);
-  if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)stream, ev, 0);
+  if (e == hipSuccess) e = hipStreamWaitEvent(stream ? (hipStream_t)stream : x->ctx->stream, ev, 0);
   (void)hipEventDestroy(ev);  // (destroyed once the recorded work has completed)
   XHIP(x, e);
   return 0;

@@ -39,7 +39,10 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
   for (int a = 0; a < 3; ++a) {
     if (fabsf(B[a]) > 1e-20f) {
       float inv = 1.0f / B[a];
-      float t1 = (P.lo[a] - A[a]) * inv, t2 = (P.hi[a] - A[a]) * inv;
+      // (the box is widened by SMK_RANGE_EPS voxels: a ray that runs ALONG a face -- the centre row of an odd
+      //  viewport along a shard boundary -- has fma(m, B, A) round onto the face for every m although
+      //  (lo - A) / B says it leaves at m = 0; the exact per-sample test decides, this only brackets it)
+      float t1 = (P.lo[a] - SMK_RANGE_EPS - A[a]) * inv, t2 = (P.hi[a] + SMK_RANGE_EPS - A[a]) * inv;
       tenter = fmaxf(tenter, fminf(t1, t2) - 2.0f);
       texit = fminf(texit, fmaxf(t1, t2) + 2.0f);
     } else if (!(A[a] >= P.lo[a] && A[a] <= P.hi[a])) {
@@ -64,12 +67,12 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
 
   float C0 = 0.f, C1 = 0.f, C2 = 0.f, C3 = 0.f;
   float first = __int_as_float(0x7f800000);
-  const int Dy = P.D[1];
+  const int Dx = P.D[0], Dy = P.D[1];
 
   // blend order: front to back (and GL_MAX, which has no order) walk m upwards; back to front
   // (VolumeRenderer.cpp:590) starts at the far plane
   const bool btf = P.blend == SMK_BLEND_BACK_TO_FRONT;
-  for (int t = 0, nt = mhi - mlo + 1; t < nt; ++t) {
+  for (int t = 0, nt = mhi >= mlo ? mhi - mlo + 1 : 0; t < nt; ++t) {  // (an all-empty wave has mlo = INT_MAX, mhi = -INT_MAX)
     const int m = btf ? mhi - t : mlo + t;
     if (!btf && !__any(m <= m1)) break;  // every ray of the wave is past its last plane (or saturated)
     if (m < m0 || m > m1) continue;
@@ -115,17 +118,21 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
     y1 = min(max(y1 - P.O[1], 0), P.D[1] - 1);
     z0 = min(max(z0 - P.O[2], 0), P.D[2] - 1);
     z1 = min(max(z1 - P.O[2], 0), P.D[2] - 1);
-    // strip-major layout: element = ((z * nsx + x / SW) * Dy + y) * SW + x % SW; the two x columns
-    // differ by one element inside a strip, by a whole strip (Dy rows) across its edge
-    const int SL = P.sw_log2, SM = (1 << SL) - 1;
-    const size_t c0 = ((size_t)(x0 >> SL) * Dy << SL) + (size_t)(x0 & SM), c1 = ((size_t)(x1 >> SL) * Dy << SL) + (size_t)(x1 & SM);
-    const size_t zs = (size_t)P.nsx * Dy << SL;  // elements per z slice
-    size_t r00 = (size_t)z0 * zs + ((size_t)y0 << SL), r10 = (size_t)z0 * zs + ((size_t)y1 << SL);
-    size_t r01 = (size_t)z1 * zs + ((size_t)y0 << SL), r11 = (size_t)z1 * zs + ((size_t)y1 << SL);
-    SmkCorner k000 = smk_load_corner<DT>(P, r00 + c0), k100 = smk_load_corner<DT>(P, r00 + c1);
-    SmkCorner k010 = smk_load_corner<DT>(P, r10 + c0), k110 = smk_load_corner<DT>(P, r10 + c1);
-    SmkCorner k001 = smk_load_corner<DT>(P, r01 + c0), k101 = smk_load_corner<DT>(P, r01 + c1);
-    SmkCorner k011 = smk_load_corner<DT>(P, r11 + c0), k111 = smk_load_corner<DT>(P, r11 + c1);
+    size_t r00 = ((size_t)z0 * Dy + y0) * Dx, r10 = ((size_t)z0 * Dy + y1) * Dx;
+    size_t r01 = ((size_t)z1 * Dy + y0) * Dx, r11 = ((size_t)z1 * Dy + y1) * Dx;
+    const size_t c0 = (size_t)x0, c1 = (size_t)x1;
+    SmkCorner k000, k100, k010, k110, k001, k101, k011, k111;
+    if constexpr (DT == 0) {
+      smk_load_pair_u8(P, r00 + c0, r00 + c1, k000, k100);
+      smk_load_pair_u8(P, r10 + c0, r10 + c1, k010, k110);
+      smk_load_pair_u8(P, r01 + c0, r01 + c1, k001, k101);
+      smk_load_pair_u8(P, r11 + c0, r11 + c1, k011, k111);
+    } else {
+      k000 = smk_load_corner<DT>(P, r00 + c0); k100 = smk_load_corner<DT>(P, r00 + c1);
+      k010 = smk_load_corner<DT>(P, r10 + c0); k110 = smk_load_corner<DT>(P, r10 + c1);
+      k001 = smk_load_corner<DT>(P, r01 + c0); k101 = smk_load_corner<DT>(P, r01 + c1);
+      k011 = smk_load_corner<DT>(P, r11 + c0); k111 = smk_load_corner<DT>(P, r11 + c1);
+    }
 
     const float sc = DT == 0 ? SMK_INV255 : 1.0f;
     float ch0 = SMK_TRI(c0), ch1 = 0.f, ch2 = 0.f, ch3 = 0.f;

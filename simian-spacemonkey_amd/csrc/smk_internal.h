@@ -11,16 +11,6 @@
 #include "../../include/smk.h"
 
 #define SMK_MAX_RANKS 8
-// HBM layout of the packed volume: STRIP-major.  A strip row is SMK_STRIP_UNITS 16-byte units =
-// one 128-byte line (8 f32 voxels / 16 u8 voxels) along the layout's contiguous axis U; the rows of
-// a strip follow each other along V, strips along U, slices along S:
-//     unit address (u, v, s) = ((s * NSu + u / SW) * Dv + v) * SW + u % SW        (SW voxels per strip row)
-// so the (u,v) window a pixel tile needs of a slice is a few strips x a run of ADJACENT 128-byte
-// lines each -- measured with tools/dma_probe.hip ("strips"): LDS-DMA streams such windows at
-// 6.4-6.7 TB/s, the row-major [s][v][u] layout of round 1 (480-byte row pieces 16 KiB apart) at 4.85.
-#define SMK_STRIP_UNITS 8
-#define SMK_STRIP_LOG2_F32 3  // voxels per strip row, log2: 8 x 16 B
-#define SMK_STRIP_LOG2_U8 4   // 16 x 8 B
 #define SMK_TIMING_RING 64
 #define SMK_STATUS_RING 8  // frames whose slice-ring status stays readable (smk_frame_failed)
 
@@ -34,8 +24,6 @@ struct RenderParams {
   int N[3];             // whole-volume dims
   int O[3];             // global index of stored voxel (0,0,0)
   int D[3];             // stored dims (region + halo)
-  int sw_log2;          // log2(voxels per strip row): 3 (f32) or 4 (u8)
-  int nsx;              // strips along x in the native layout (S=z, U=x, V=y): ceil(D[0] / 2^sw_log2)
   float lo[3], hi[3];   // region in voxel coordinates: [g0-.5, g1-.5)
   int top[3];           // region touches the volume's top face on this axis (inclusive)
   int cplane_on;        // free clip plane: a sample stays when fma-chain(cplane . (p,1)) >= 0 (voxel coordinates)
@@ -93,6 +81,7 @@ struct SlabAux {
   // per-tile workgroup durations of an earlier frame: the schedule's weights
   unsigned *d_ticks = nullptr, *h_ticks = nullptr;  // device buffer the kernel writes; pinned copy in flight
   int ticks_cap = 0, ticks_pending_n = 0, ticks_age = 0, ticks_adopted = 0;
+  int ticks_n_last = 0;  // tiles of the latest slice-ring launch (d_ticks holds [3][that many] words)
   bool ticks_pending = false;
   long long ticks_pending_sig = 0, ticks_good_sig = -1;
   hipEvent_t ticks_ev = nullptr;
@@ -124,9 +113,7 @@ struct smk_ctx {
   int cplane_on = 0;  // free clip plane (glClipPlane), eye space
   double cplane_eye[4] = {0, 0, 0, 0};
   void *d_vox = nullptr;
-  // lazily built re-orderings for the slice-ring kernel, same strip-major scheme with other axes:
-  void *d_vox_x = nullptr;  // S = x, U = y, V = z (views whose principal axis is x)
-  void *d_vox_y = nullptr;  // S = y, U = x, V = z (principal axis y)
+  void *d_vox_x = nullptr;  // x-major copy [x][z][y] for views whose principal axis is x (lazy)
   std::string slab_why;     // why the last frame fell back to the gather kernel ("" if it did not)
   uint32_t *d_nrm = nullptr;
   bool have_normals = false;
@@ -200,6 +187,6 @@ struct smk_ctx {
 hipError_t smk_launch_gather(const RenderParams &P, int dtype, int tf_mode, int shade_kind,
                              hipStream_t s);
 // returns hipErrorNotSupported (and *why) when the frame must use the gather kernel
-// vox_by_perm[0..2]: the layouts for S = z / y / x (null = not built yet: *why says which)
-hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T, int opt_tile, int forced,
-                           const void *const vox_by_perm[3], SlabAux *aux, const char **why, hipStream_t s);
+hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kind, int opt_T, int opt_tile, int forced,
+                           const void *vox_native, const void *vox_xmajor, SlabAux *aux, const char **why,
+                           hipStream_t s);

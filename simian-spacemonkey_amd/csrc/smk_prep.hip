@@ -593,13 +593,211 @@ __global__ __launch_bounds__(256) void smk_k_synth(int kind, uint32_t seed, int 
   }
 }
 
+// ------------------------------------------------------------------------------ genvol on the GPU
+// kind 1: the reference's test-volume generator, `genvol -spheres 4 -p 10 -pscale .7 -pwrap 3 3 3
+// -pabs -blur -bw 1 1 1 .7` (genvol/scripts/make64.bat:1; SURVEY 8d's input for configs 2-5):
+//   makeSpheres (genvol/main.cpp:212-256): r = min(|p - 1/2|, .48) + perl(p), clamped to [0, .5];
+//       val = (int)(2 r n); voxel = (n - val) * (255 / n)
+//   perl (main.cpp:153-165) with -pabs: PerlinNoise3Dabs(p * wrap, alpha 2, beta 2, 10 harmonics) * pscale
+//       (genvol/perlin.c:76-124 noise3, :246-263 the absolute-value harmonic sum); double precision
+//   blur (main.cpp:334-430): 27-tap, weights bw0, bw1/6, bw2/12, bw3/8, divisor bw0+bw1+bw2+bw3
+// Bytes identical to the CPU checker's restatement (itself pinned against the reference's perlin.c):
+// every operation keeps the C source's type (float where it is float, double where it is double),
+// -ffp-contract=off.  The Perlin tables come from libc's rand() in the reference (srand(seed), perlin.c
+// :145-176, drawn TWICE: genvol's main calls init(), and noise3's `start` flag runs it again on the
+// first call, perlin.c:84-87); glibc's TYPE_3 generator is restated below so the volume does not
+// depend on the host's libc.
+namespace {
+struct GenvolTables {
+  int p[514];
+  double g3[514][3];
+};
+
+struct GlibcRand {  // glibc random_r TYPE_3: r[k] = r[k-31] + r[k-3] (mod 2^32), output >> 1, after 310 discarded draws
+  uint32_t ring[34];
+  int pos = 0;
+  explicit GlibcRand(unsigned seed) {
+    int32_t r[344];
+    if (seed == 0) seed = 1;
+    r[0] = (int32_t)seed;
+    for (int i = 1; i < 31; ++i) {
+      long long w = (16807LL * r[i - 1]) % 2147483647LL;
+      if (w < 0) w += 2147483647LL;
+      r[i] = (int32_t)w;
+    }
+    for (int i = 31; i < 34; ++i) r[i] = r[i - 31];
+    for (int i = 34; i < 344; ++i) r[i] = (int32_t)((uint32_t)r[i - 31] + (uint32_t)r[i - 3]);
+    for (int i = 0; i < 34; ++i) ring[i] = (uint32_t)r[310 + i];
+  }
+  int next() {
+    uint32_t v = ring[(pos + 34 - 31) % 34] + ring[(pos + 34 - 3) % 34];
+    ring[pos] = v;
+    pos = (pos + 1) % 34;
+    return (int)(v >> 1);
+  }
+};
+
+void genvol_perlin_init(GlibcRand &rnd, GenvolTables &T) {  // perlin.c:145-176 (the 1-D and 2-D tables only consume draws)
+  const int B = 0x100;
+  int i, j, k;
+  for (i = 0; i < B; i++) {
+    T.p[i] = i;
+    (void)rnd.next();                          // g1[i]
+    for (j = 0; j < 2; j++) (void)rnd.next();  // g2[i]
+    for (j = 0; j < 3; j++) T.g3[i][j] = (double)((rnd.next() % (B + B)) - B) / B;
+    const double s = sqrt(T.g3[i][0] * T.g3[i][0] + T.g3[i][1] * T.g3[i][1] + T.g3[i][2] * T.g3[i][2]);
+    for (j = 0; j < 3; j++) T.g3[i][j] /= s;
+  }
+  while (--i) {
+    k = T.p[i];
+    T.p[i] = T.p[j = rnd.next() % B];
+    T.p[j] = k;
+  }
+  for (i = 0; i < B + 2; i++) {
+    T.p[B + i] = T.p[i];
+    for (j = 0; j < 3; j++) T.g3[B + i][j] = T.g3[i][j];
+  }
+}
+}  // namespace
+
+__device__ __forceinline__ double gv_noise3(const int *pp, const double (*pg3)[3], const double vec[3]) {
+  int b0[3], b1[3];
+  double r0[3], r1[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double t = vec[a] + 4096.0;  // N = 0x1000
+    b0[a] = ((int)t) & 0xff;
+    b1[a] = (b0[a] + 1) & 0xff;
+    r0[a] = t - (int)t;
+    r1[a] = r0[a] - 1.;
+  }
+  const int i = pp[b0[0]], j = pp[b1[0]];
+  const int b00 = pp[i + b0[1]], b10 = pp[j + b0[1]], b01 = pp[i + b1[1]], b11 = pp[j + b1[1]];
+  const double t = r0[0] * r0[0] * (3. - 2. * r0[0]);
+  const double sy = r0[1] * r0[1] * (3. - 2. * r0[1]);
+  const double sz = r0[2] * r0[2] * (3. - 2. * r0[2]);
+  const double *q;
+  double u, v, a, b, c, d;
+#define AT3(rx, ry, rz) (rx * q[0] + ry * q[1] + rz * q[2])
+#define LERP(t, a, b) (a + t * (b - a))
+  q = pg3[b00 + b0[2]]; u = AT3(r0[0], r0[1], r0[2]);
+  q = pg3[b10 + b0[2]]; v = AT3(r1[0], r0[1], r0[2]);
+  a = LERP(t, u, v);
+  q = pg3[b01 + b0[2]]; u = AT3(r0[0], r1[1], r0[2]);
+  q = pg3[b11 + b0[2]]; v = AT3(r1[0], r1[1], r0[2]);
+  b = LERP(t, u, v);
+  c = LERP(sy, a, b);
+  q = pg3[b00 + b1[2]]; u = AT3(r0[0], r0[1], r1[2]);
+  q = pg3[b10 + b1[2]]; v = AT3(r1[0], r0[1], r1[2]);
+  a = LERP(t, u, v);
+  q = pg3[b01 + b1[2]]; u = AT3(r0[0], r1[1], r1[2]);
+  q = pg3[b11 + b1[2]]; v = AT3(r1[0], r1[1], r1[2]);
+  b = LERP(t, u, v);
+  d = LERP(sy, a, b);
+  return LERP(sz, c, d);
+#undef AT3
+#undef LERP
+}
+
+// makeSpheres with the -pabs perturbation; tables staged in LDS (14.4 KB)
+__global__ __launch_bounds__(256) void smk_k_genvol_spheres(const GenvolTables *tab, int sx, int sy, int sz, int nspheres, int pharm,
+                                                            double pscale, float w0, float w1, float w2, float palpha, float pbeta,
+                                                            unsigned char *out) {
+  __shared__ int pp[514];
+  __shared__ double pg3[514][3];
+  for (int e = threadIdx.x; e < 514; e += 256) {
+    pp[e] = tab->p[e];
+    pg3[e][0] = tab->g3[e][0];
+    pg3[e][1] = tab->g3[e][1];
+    pg3[e][2] = tab->g3[e][2];
+  }
+  __syncthreads();
+  const float dd = 255 / (float)nspheres;
+  const float dx = 1 / (float)sx, dy = 1 / (float)sy, dz = 1 / (float)sz;
+  const size_t n = (size_t)sx * sy * sz;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(t % sx), j = (int)((t / sx) % sy), i = (int)(t / ((size_t)sx * sy));
+    const float p[3] = {k * dx, j * dy, i * dz};
+    const float v[3] = {p[0] - .5f, p[1] - .5f, p[2] - .5f};
+    const float nv = (float)sqrt((double)(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]));  // normV3
+    float r = (float)(((double)nv < .48) ? (double)nv : .48);
+    {
+      // PerlinNoise3Dabs(x * wrap, alpha, beta, n) * pscale (perlin.c:246-263)
+      double q[3] = {(double)p[0] * w0, (double)p[1] * w1, (double)p[2] * w2};
+      double sum = 0, scale = 1;
+      for (int h = 0; h < pharm; h++) {
+        double val = gv_noise3(pp, pg3, q);
+        val = val < 0 ? -val : val;
+        sum += val / scale;
+        scale *= palpha;
+        q[0] *= pbeta;
+        q[1] *= pbeta;
+        q[2] *= pbeta;
+      }
+      r += (float)(sum * pscale);
+      const double rd = r;
+      r = (float)(rd > 0 ? (rd < .5 ? rd : .5) : 0);  // CLAMP_ARB(0, r, .5)
+    }
+    const int val = (int)(r * 2 * nspheres);
+    out[t] = (unsigned char)(int)((double)((nspheres - val) * dd));
+  }
+}
+
+// blur as a gather: the reference scatters every interior voxel's weighted value into its 27
+// neighbours in voxel order (i, j, k ascending); a target therefore receives its contributions in
+// ascending order of the SOURCE index, i.e. descending offset -- kept here, so the float sums round alike
+__global__ __launch_bounds__(256) void smk_k_genvol_blur(const unsigned char *in, int sx, int sy, int sz, float bw0, float bw1, float bw2,
+                                                         float bw3, unsigned char *out) {
+  const size_t n = (size_t)sx * sy * sz;
+  const float div = bw0 + bw1 + bw2 + bw3;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(t % sx), j = (int)((t / sx) % sy), i = (int)(t / ((size_t)sx * sy));
+    float acc = 0.f;
+    for (int di = 1; di >= -1; --di)
+      for (int dj = 1; dj >= -1; --dj)
+        for (int dk = 1; dk >= -1; --dk) {
+          const int si = i - di, sj = j - dj, sk = k - dk;  // the source whose offset (di, dj, dk) lands here
+          if (si < 1 || si > sz - 2 || sj < 1 || sj > sy - 2 || sk < 1 || sk > sx - 2) continue;
+          const double d = in[((size_t)si * sy + sj) * sx + sk] / 255.0;
+          const int nz = (di != 0) + (dj != 0) + (dk != 0);
+          acc += nz == 0 ? (float)(d * bw0) : nz == 1 ? (float)(d * bw1 / 6.0) : nz == 2 ? (float)(d * bw2 / 12.0) : (float)(d * bw3 / 8.0);
+        }
+    const double c = acc / div;
+    out[t] = (unsigned char)(int)((c > 0 ? (c < 1 ? c : 1) : 0) * 255);
+  }
+}
+
+static int genvol_spheres_device(smk_ctx *c, unsigned seed, int sx, int sy, int sz, unsigned char *out) {
+  GenvolTables T;
+  GlibcRand rnd(seed);
+  genvol_perlin_init(rnd, T);  // genvol main's init() (genvol/main.cpp:118-120)
+  genvol_perlin_init(rnd, T);  // noise3's own first-call init (perlin.c:84-87): these are the tables in use
+  GenvolTables *d_tab = nullptr;
+  unsigned char *d_tmp = nullptr;
+  const size_t n = (size_t)sx * sy * sz;
+  PCHK(c, hipMalloc((void **)&d_tab, sizeof T));
+  PCHK(c, hipMalloc((void **)&d_tmp, n));
+  PCHK(c, hipMemcpy(d_tab, &T, sizeof T, hipMemcpyHostToDevice));
+  const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(smk_k_genvol_spheres, dim3(blocks), dim3(256), 0, c->stream, (const GenvolTables *)d_tab, sx, sy, sz, 4, 10, .7, 3.f, 3.f, 3.f,
+                     2.f, 2.f, d_tmp);
+  hipLaunchKernelGGL(smk_k_genvol_blur, dim3(blocks), dim3(256), 0, c->stream, (const unsigned char *)d_tmp, sx, sy, sz, 1.f, 1.f, 1.f, .7f, out);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d_tab);
+  (void)hipFree(d_tmp);
+  PCHK(c, e);
+  return 0;
+}
+
 extern "C" int smk_synth_volume_device(smk_ctx *c, int kind, unsigned seed, int sx, int sy, int sz, void *out) {
   if (!c) return 1;
   PCHK(c, hipSetDevice(c->device));
-  if (!out || kind != 0 || sx < 1 || sy < 1 || sz < 1) {
-    c->err = "smk_synth_volume_device: bad arguments (kind must be 0)";
+  if (!out || (kind != 0 && kind != 1) || sx < 1 || sy < 1 || sz < 1) {
+    c->err = "smk_synth_volume_device: bad arguments (kind 0: smooth noisy shells, 1: genvol spheres)";
     return 1;
   }
+  if (kind == 1) return genvol_spheres_device(c, seed, sx, sy, sz, (unsigned char *)out);
   size_t n = (size_t)sx * sy * sz;
   unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
   hipLaunchKernelGGL(smk_k_synth, dim3(blocks), dim3(256), 0, c->stream, kind, seed, sx, sy, sz, (unsigned char *)out);

@@ -40,18 +40,14 @@
 
 // wave-uniform description of one launch
 struct SlabParams {
-  int perm;                    // 0: S=z (U=x,V=y; native)  1: S=y (U=x,V=z; y-major copy)  2: S=x (U=y,V=z; x-major copy)
+  int perm;                    // 0: S=z (U=x,V=y)  1: S=y (U=x,V=z)  2: S=x (U=y,V=z; x-major copy)
   int au, av, as;              // model-axis index of U, V, S
-  // strip-major layout in use (smk_internal.h): a strip row = 128 B, the rows of a strip are adjacent
-  // along V, strips follow along U, slices along S
-  unsigned stripStrideB;       // bytes from one strip to the next = Dv * 128
-  long long strideSb;          // bytes from one slice to the next = NSu * Dv * 128
-  int DuPad;                   // stored U extent padded to whole strips (voxels)
+  long long strideV, strideS;  // voxel strides of the layout in use (U stride is 1)
   int Ou, Ov, Os;              // stored-box origin along U,V,S (global voxel index)
   int Du, Dv, Ds;              // stored-box dims along U,V,S
   int wu;                      // 16-byte units per window row that are loaded at most (<= wp)
   int wv;                      // window rows that are loaded
-  int wp;                      // LDS row pitch in 16-byte units, a multiple of 4 with wp / gcd(64, wp) <= 7: the slot image is flat with this
+  int wp;                      // LDS row pitch in 16-byte units, a multiple of 8: the slot image is flat with this
                                // pitch, so the (row, column) a DMA lane serves repeats every `per` chunks = `rpg` rows
   int per, rpg;                // chunks and rows per group: per = wp / gcd(64, wp), rpg = 64 / gcd(64, wp)
   int groups;                  // row groups per slice = ceil(wv / rpg); chunks = groups * per
@@ -69,7 +65,10 @@ struct SlabParams {
   int use_occ;                 // (V,G) occupancy bitmap copied to LDS
   int fast_tf;                 // alpha-first classification with 8-byte texel loads (no third axis, or use_ah)
   const int *order;            // tile of each block (work-balanced schedule, -1 = none), see smk_launch_slab
-  unsigned *tile_ticks;        // [ntiles] duration of each tile's workgroup in 100 MHz ticks (next frame's weights)
+  unsigned *tile_ticks;        // [3][ntiles]: duration of each tile's workgroup in 100 MHz ticks (next frame's weights) |
+                               // slices its loaders streamed | slices of its range (the loaders stop once every ray of
+                               // the tile is saturated: what was NOT streamed is not counted as read, smk_last_frame_info)
+  int ntiles;
   int *status;                 // host-visible word: 1 = protocol time-out, 2 = window bound violated
   float *diag;                 // [16] diagnostic counters (lockstep bit 16) or null
   unsigned *trace;             // [nblocks][8] per-workgroup timeline record (lockstep bit 32, see smk.h) or null
@@ -226,14 +225,15 @@ __device__ __forceinline__ float slab_tex_chan(const SlabTexel4 &x, int k) {
 // last NL waves are loaders: loader l streams DMA chunks l, l+NL, ... of every slice.
 // second launch-bound = waves per SIMD wanted: workgroups of 5/9/10 waves only double up on a CU
 // (2 x 9 waves = 5 on one SIMD) if the kernel stays within 96 VGPRs
-template <int DT, int SH, int PERM, int NW, int NL, bool DIAG>
+// TF: 1 = 2-D (V,G) table x optional third-axis alpha (NV20VolRen3D.cpp:544-596), 2 = dense 3-D (v,g,h)
+// table (TFWidgetRen.cpp:779-845; BASELINE configs 4/5)
+template <int DT, int SH, int PERM, int NW, int NL, bool DIAG, int TF = 1>
 __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) == 5 || (NW + NL) == 10) ? 5 : ((NW + NL) == 11 ? 3 : 4)) void smk_k_slab(const RenderParams P, const SlabParams Q) {
   constexpr int UPV = DT == 0 ? 2 : 1;   // voxels per 16-byte DMA unit
   constexpr int VB = DT == 0 ? 8 : 16;   // bytes per voxel
   // (global_load_lds_dwordx3 does NOT compact: it writes 12 bytes per lane at a 16-byte lane stride
   //  -- tools/dma_layout_probe.hip -- so staging only {c0,c1,c2} needs a 12-byte HBM plane)
   constexpr int VBL = DT == 0 ? 3 : 4;   // log2
-  constexpr int SWV = SMK_STRIP_UNITS * UPV;  // voxels per strip row
   constexpr int NTH = (NW + NL) * 64;
   // big workgroups (one per CU, 128 VGPRs each): read whole voxels, release ring slots early
   constexpr bool EARLY = (NW + NL) > 10;
@@ -287,7 +287,10 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   for (int a = 0; a < 3; ++a) {
     if (fabsf(B[a]) > 1e-20f) {
       float inv = 1.0f / B[a];
-      float t1 = (P.lo[a] - A[a]) * inv, t2 = (P.hi[a] - A[a]) * inv;
+      // (the box is widened by SMK_RANGE_EPS voxels: a ray that runs ALONG a face -- the centre row of an odd
+      //  viewport along a shard boundary -- has fma(m, B, A) round onto the face for every m although
+      //  (lo - A) / B says it leaves at m = 0; the exact per-sample test decides, this only brackets it)
+      float t1 = (P.lo[a] - SMK_RANGE_EPS - A[a]) * inv, t2 = (P.hi[a] + SMK_RANGE_EPS - A[a]) * inv;
       tenter = fmaxf(tenter, fminf(t1, t2) - 2.0f);
       texit = fminf(texit, fmaxf(t1, t2) + 2.0f);
     } else if (!(A[a] >= P.lo[a] && A[a] <= P.hi[a])) {
@@ -428,9 +431,9 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       v0 = max(v0 - Q.Ov, 0);
       u1 = min(u1 - Q.Ou, Q.Du - 1);
       v1 = min(v1 - Q.Ov, Q.Dv - 1);
-      u0 &= ~(SWV / 2 - 1);  // windows start on half strips (64 B)
-      // fixed-shape window: slide it back inside the stored box (padded to whole strips) where it would stick out
-      const int wu0 = min(u0, Q.DuPad - wuv), wv0 = min(v0, Q.Dv - Q.wv);
+      if (UPV == 2) u0 &= ~1;  // rows start on whole 16-byte units (the stored U extent is even)
+      // fixed-shape window: slide it back inside the stored box where it would stick out
+      const int wu0 = min(u0, Q.Du - wuv), wv0 = min(v0, Q.Dv - Q.wv);
       if (u1 - wu0 + 1 > wuv || v1 - wv0 + 1 > Q.wv) ctl[3] = 2;  // host bound violated: reported, never silent
       // what this slice really needs of the fixed-shape window (the loader masks the rest)
       const int need_u = max((u1 - wu0 + UPV) / UPV, 1), need_v = max(v1 - wv0 + 1, 1);
@@ -473,25 +476,18 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       const int per = Q.per, rpg = Q.rpg, groups = Q.groups;
       const int mygroups = (groups - lid + NL - 1) / NL;
       const int mych = mygroups * per;  // DMA wave-instructions of a whole window (this loader's share)
-      constexpr unsigned strideVb = SMK_STRIP_UNITS * 16u;  // a window row advances one 128-byte line inside every strip
-      // unit 64*k + lane of a group sits at (row, column) = divmod(64*k + lane, wp): fixed per lane and phase k;
-      // column c (units from the window's strip-aligned origin) lives in strip c / 8, unit c % 8 of that strip's row
-      // Windows start on HALF strips (64 B: alignment to whole strips costs a strip of LDS per row, and the
-      // ring's depth is what the frame time hangs on): two static offset sets, origin at a strip's first /
-      // fifth unit; a slice picks one by its origin's parity.  Inner strips are read as whole 128-byte lines
-      // either way, only the window's outer half strips as 64-byte pieces.
-      unsigned voffA[7], voffB[7], rowk[7], colk[7];
+      const unsigned strideVb = (unsigned)(Q.strideV * (long long)VB);  // bytes, < 2^32
+      // unit 64*k + lane of a group sits at (row, column) = divmod(64*k + lane, wp): fixed per lane and phase k
+      unsigned voff[7], rowk[7], colk[7];
 #pragma unroll
       for (int k = 0; k < 7; ++k) {
         const unsigned g = 64u * k + lane;
         rowk[k] = g / (unsigned)Q.wp;
         colk[k] = g - rowk[k] * (unsigned)Q.wp;
-        const unsigned cb = colk[k] + SMK_STRIP_UNITS / 2;
-        voffA[k] = rowk[k] * strideVb + (colk[k] / SMK_STRIP_UNITS) * Q.stripStrideB + (colk[k] % SMK_STRIP_UNITS) * 16u;
-        voffB[k] = rowk[k] * strideVb + (cb / SMK_STRIP_UNITS) * Q.stripStrideB + (cb % SMK_STRIP_UNITS) * 16u;
+        voff[k] = rowk[k] * strideVb + colk[k] * 16u;
       }
       const size_t gstep = (size_t)(NL * rpg) * strideVb;  // source advance from one of my groups to the next
-      const size_t strideSb = (size_t)Q.strideSb;
+      const size_t strideSb = (size_t)Q.strideS * VB;
       const bool l2hot = DIAG && (P.lockstep & 8) != 0;           // (diagnostic: every slice re-reads one slice)
       int q = 0, inflight = 0, landed = 0, idle = 0, minp = 0, slot_q = 0, fly_total = 0;
       int fly_counts = 0;  // lane (q & 63): DMA wave-instructions of load index q (a scalar array in one VGPR)
@@ -514,26 +510,40 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
                : "=&s"(keep_m0)                                                                                     \
                : "v"(voff_), "s"(dst_), "s"(src_)                                                                   \
                : "memory")
-      // table entries of 64 consecutive load indices, one per lane, refreshed every 64 slices: a
-      // slice's window origin is then one v_readlane away instead of an LDS round trip, and the 64-bit
-      // source offset of this loader's first group of that slice is computed there, 64 slices per
-      // instruction, instead of ~25 scalar instructions per slice
+      // table entries of 64 consecutive load indices, one per lane, refreshed every 64 slices:
+      // a slice's window origin is then one v_readlane away instead of an LDS round trip
+      // (Measured and dropped in round 2: the 64-bit source offset as two more lane arrays, and the
+      //  column masks cached across slices in a VGPR bit set -- 1024^3 3.54 -> 3.74 ms: the scalar
+      //  per-slice arithmetic below is cheaper than it looks, the extra VALU is not.)
       int ent_uv = 0;
-      unsigned ent_lo = 0, ent_hi = 0;
-      // per-slice state that rarely changes from one slice to the next is kept across slices and redone
-      // only when its key moves: the offset set (the window origin's half-strip parity flips every ~10
-      // slices) and the column masks (what a slice needs of the window's width)
-      unsigned voff[7];
-      bool cm[7];
-      unsigned long long mk[7];  // the column masks as wave-uniform lane masks (EXEC values)
-#pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        voff[k] = voffA[k];
-        cm[k] = false;
-        mk[k] = 0;
-      }
-      bool last_odd = false;
-      unsigned last_need_u = 0xffffffffu;
+      // EAGER PUBLICATION.  A slice used to be published when its loader, done issuing the NEXT one, waited
+      // for it -- up to a slice's issue time (~0.5 us) after it had landed, on a ring that is a few slices
+      // deep.  The wave's outstanding vector-memory count can be READ (s_getreg HW_REG_IB_STS: VM_CNT in
+      // bits [3:0], its two high bits in [23:22]; tools/vmcnt_probe.hip), and the DMAs complete in order:
+      // after every group of chunks the loader looks, and publishes each in-flight slice whose last
+      // instruction is no longer outstanding.  `cur` = instructions of the slice being issued so far
+      // (younger than everything in flight).  The blocking wait stays for when nothing can be issued.
+#ifndef SLAB_EAGER
+#define SLAB_EAGER 1
+#endif
+      // (big workgroups only: on the small ones' deep ring a late word costs little, and the look costs
+      //  the kernel scalar registers -- 97 spilled SGPRs against 39)
+      constexpr bool EAGER = SLAB_EAGER && EARLY;
+      auto publish_landed = [&](int cur) {
+        if (!EAGER || inflight == 0) return;
+        const unsigned st = __builtin_amdgcn_s_getreg((31 << 11) | 7);
+        const int out = (int)((st & 0xfu) | (((st >> 22) & 3u) << 4));
+        const int before = landed;
+        while (inflight > 0) {
+          const int c_old = FIFO ? __builtin_amdgcn_readlane(fly_counts, (q - inflight) & 63) : mych;
+          const int younger = (FIFO ? fly_total : mych * inflight) - c_old + cur;
+          if (out > younger) break;
+          if (FIFO) fly_total -= c_old;
+          --inflight;
+          ++landed;
+        }
+        if (landed != before) raw_lds_st_b32(&ctl[4 + lid], landed);
+      };
       const bool prof = DIAG && (P.lockstep & 48) != 0 && Q.diag != nullptr;  // (diagnostic: where a loader's cycles go)
       long long t_issue = 0, t_wait = 0, t_idle = 0, t_mark = 0;
       const long long t_start = prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -555,16 +565,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             const int ql = q + lane;
             const int e = (dir > 0 ? smin + ql : smax + 1 - ql) - Q.Os;
             ent_uv = -1;
-            if (ql <= npos && e >= 0 && e < Q.Ds) {
-              ent_uv = (int)raw_lds_b64(&wtab[e]).y;  // (.pack; never -1: u0 < 2^11)
-              // (u0 is a whole number of half strips, see the table: the base is its strip, the parity picks the offsets)
-              const unsigned eu0 = (unsigned)ent_uv & 0x7ffu, ev0 = ((unsigned)ent_uv >> 11) & 0x7ffu;
-              const unsigned long long off = (l2hot ? 0ull : (unsigned long long)e * (unsigned long long)strideSb) +
-                                             (unsigned long long)(eu0 / (unsigned)SWV) * Q.stripStrideB +
-                                             (unsigned long long)(ev0 + (unsigned)(lid * rpg)) * strideVb;
-              ent_lo = (unsigned)off;
-              ent_hi = (unsigned)(off >> 32);
-            }
+            if (ql <= npos && e >= 0 && e < Q.Ds) ent_uv = (int)raw_lds_b64(&wtab[e]).y;  // (.pack; never -1: u0 < 2^11)
           }
           const int uv = __builtin_amdgcn_readlane(ent_uv, q & 63);
           int issued = 0;  // DMA wave-instructions of this slice (this loader's share)
@@ -573,14 +574,10 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             // (small windows: the whole shape -- the saving would not pay for the partial-group path)
             const unsigned need_u = Q.mask_need ? (((unsigned)uv >> 22) & 0x3fu) + 1u : (unsigned)Q.wu;
             const unsigned need_v = Q.mask_need ? (unsigned)Q.wv - ((unsigned)uv >> 28) * (unsigned)((Q.wv + 15) / 16) : (unsigned)Q.wv;
-            const char *src = gv + (((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ent_hi, q & 63) << 32) |
-                                    (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ent_lo, q & 63));
-            const bool odd_half = ((unsigned)uv & (unsigned)(SWV / 2)) != 0;  // wave-uniform (bit of u0)
-            if (odd_half != last_odd) {
-              last_odd = odd_half;
-#pragma unroll
-              for (int k = 0; k < 7; ++k) voff[k] = odd_half ? voffB[k] : voffA[k];
-            }
+            const int sl = (dir > 0 ? smin + q : smax + 1 - q) - Q.Os;
+            const unsigned u0 = (unsigned)uv & 0x7ffu, v0 = ((unsigned)uv >> 11) & 0x7ffu;
+            const char *src = gv + (l2hot ? (size_t)0 : (size_t)sl * strideSb) + ((size_t)v0 * strideVb + (size_t)u0 * VB) +  // (64-bit: v0 * strideVb passes 4 GiB when V is the slowest axis of a 1024^3 volume)
+                              (size_t)(lid * rpg) * strideVb;
             unsigned dst = dst0, row0 = (unsigned)(lid * rpg);
             // per = wp / gcd(64, wp) is 1, 3, 5 or 7 (the host picks such a pitch)
 #define SLAB_GROUP(CHUNK)              \
@@ -598,19 +595,17 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             // only the group the needed rows end in pays a per-lane row test (lane 0 always loads
             // there, so that a group is `per` wave-instructions: the in-order vmcnt counts slices
             // through the per-slice instruction counts kept in fly_counts).
-            if (need_u != last_need_u) {
-              last_need_u = need_u;
+            bool cm[7];
+            unsigned long long mk[7];  // the same column masks as wave-uniform lane masks (EXEC values)
 #pragma unroll
-              for (int k = 0; k < 7; ++k) {
-                cm[k] = k < per && colk[k] < need_u;
-                mk[k] = __builtin_amdgcn_ballot_w64(cm[k]);
-              }
+            for (int k = 0; k < 7; ++k) {
+              cm[k] = k < per && colk[k] < need_u;
+              mk[k] = __builtin_amdgcn_ballot_w64(cm[k]);
             }
+#define CM(k) cm[k]
             for (int g = 0; g < mygroups; ++g) {
-              if (FIFO) {
-                if (row0 >= need_v) break;  // nothing of this group (or the following ones) is needed: not issued, not counted
-                issued += per;
-              }
+              if (FIFO && row0 >= need_v) break;  // nothing of this group (or the following ones) is needed: not issued, not counted
+              issued += per;
               if (row0 + (unsigned)rpg <= need_v) {
                 if (per == 3) {
                   // a whole group in ONE statement: EXEC takes each chunk's column mask in turn, M0 steps
@@ -626,16 +621,24 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
                                : [dst] "s"(dst), [src] "s"(src), [e0] "s"(mk[0]), [e1] "s"(mk[1]), [e2] "s"(mk[2]), [v0] "v"(voff[0]),
                                  [v1] "v"(voff[1]), [v2] "v"(voff[2])
                                : "memory", "scc");
+                } else if (per == 1) {  // one chunk per group (pitches 8, 16, 32, 64): the same, once
+                  unsigned long long keep_exec;
+                  asm volatile("s_mov_b32 %[km], m0\n\ts_mov_b64 %[ke], exec\n\ts_mov_b32 m0, %[dst]\n\t"
+                               "s_mov_b64 exec, %[e0]\n\tglobal_load_lds_dwordx4 %[v0], %[src]" SLAB_DMA_POLICY "\n\t"
+                               "s_mov_b64 exec, %[ke]\n\ts_mov_b32 m0, %[km]"
+                               : [km] "=&s"(keep_m0), [ke] "=&s"(keep_exec)
+                               : [dst] "s"(dst), [src] "s"(src), [e0] "s"(mk[0]), [v0] "v"(voff[0])
+                               : "memory", "scc");
                 } else {
 #define SLAB_CHUNK_ROWS_OK(k) \
-  if (cm[k]) SLAB_DMA(src, dst + k * 1024u, voff[k]);
+  if (CM(k)) SLAB_DMA(src, dst + k * 1024u, voff[k]);
                   SLAB_GROUP(SLAB_CHUNK_ROWS_OK)
 #undef SLAB_CHUNK_ROWS_OK
                 }
               } else {
 #define SLAB_CHUNK_MASKED(k)                                                                  \
   {                                                                                           \
-    const bool in_need = cm[k] && row0 + rowk[k] < need_v;                                    \
+    const bool in_need = CM(k) && row0 + rowk[k] < need_v;                                    \
     const unsigned vo = in_need ? voff[k] : 0u; /* lane 0 re-reads the group's first unit */  \
     if (in_need || lane == 0) SLAB_DMA(src, dst + k * 1024u, vo);                             \
   }
@@ -645,13 +648,15 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
               src += gstep;
               dst += (unsigned)(NL * per * 1024);
               row0 += (unsigned)(NL * rpg);
+              publish_landed(issued);
             }
 #undef SLAB_GROUP
+#undef CM
           } else if (!FIFO) {
             // slice outside the stored box (never read): uniform counting wants its instructions all the same
             unsigned dst = dst0;
             for (int c = 0; c < mych; ++c) {
-              SLAB_DMA(gv, dst, voffA[0] * 0u);
+              SLAB_DMA(gv, dst, voff[0] * 0u);
               dst += 1024u;
             }
           }
@@ -669,6 +674,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           t_mark = t;
         }
         if (stop) break;
+        publish_landed(0);
+        if (EAGER && inflight < Q.maxfly && q <= npos && q - nslots < minp) continue;  // room again: issue on
         if (inflight > 0) {
           // retire the oldest slice in flight: everything but the younger slices' DMAs is done
           if (FIFO) {
@@ -776,8 +783,18 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           }
           have = __builtin_amdgcn_readfirstlane(have);
         }
+        // (Measured and dropped: SLAB_REPS samples per lane and turn of the loop, to pay the loop's own
+        //  cost -- progress word, poll, flow control -- once per two or three samples.  512^3 f32 frame,
+        //  REPS 1 / 2 / 3: 1.89 / 2.02 / 1.97 ms; the scalar instruction count did not move (4.74e8 ->
+        //  4.81e8) and the vector one rose 12 %: lanes whose next slices have not landed sit the extra
+        //  sample out, so the second body mostly runs with few lanes.  Kept as a build knob.)
+#ifndef SLAB_REPS
+#define SLAB_REPS 1
+#endif
+#pragma unroll
+        for (int rep = 0; rep < (EARLY ? 1 : SLAB_REPS); ++rep) {
         const bool act = pb < SLAB_DONE && pb + 2 <= have;
-        if (count) {
+        if (count && rep == 0) {
           n_lead += (float)(have - pos);
           n_wstep += (float)Q.wstep;
         }
@@ -831,7 +848,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 #define E2(dx, dy, dz) rq[QI(dx, dy, dz)].z
             ch0 = TRI(E0);
             ch1 = TRI(E1);
-            if (P.third_axis) ch2 = TRI(E2);
+            if (TF == 2 || P.third_axis) ch2 = TRI(E2);
 #undef E2
 #undef E1
 #undef E0
@@ -842,7 +859,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 #define E3(dx, dy, dz) smk_ub(rq[QI(dx, dy, dz)].x, 3)
             ch0 = TRI(E0) * SMK_INV255;
             ch1 = TRI(E1) * SMK_INV255;
-            if (P.third_axis) {
+            if (TF == 2 || P.third_axis) {
               ch2 = TRI(E2) * SMK_INV255;
               if (P.nelts == 4) ch3 = TRI(E3) * SMK_INV255;
             }
@@ -851,7 +868,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 #undef E1
 #undef E0
           } else if constexpr (DT == 1) {
-            if (P.third_axis) {
+            if (TF == 2 || P.third_axis) {
               v3f q[8];
               slab_read8(a0, a0 + pitch_b, b0, b0 + pitch_b, q);
 #define E0(dx, dy, dz) q[QI(dx, dy, dz)].x
@@ -878,7 +895,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 #define E3(dx, dy, dz) smk_ub(q[QI(dx, dy, dz)], 3)
             ch0 = TRI(E0) * SMK_INV255;
             ch1 = TRI(E1) * SMK_INV255;
-            if (P.third_axis) {
+            if (TF == 2 || P.third_axis) {
               ch2 = TRI(E2) * SMK_INV255;
               if (P.nelts == 4) ch3 = TRI(E3) * SMK_INV255;
             }
@@ -891,7 +908,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           float4 col;
           bool hit;
           SlabTexel4 tx4 = {0, 0, 0, 0, 0.f, 0.f};
-          if (Q.fast_tf) {
+          if (TF == 1 && Q.fast_tf) {
             int s0, s1, t0, t1;
             float fs, ft;
             smk_lin_clamp(__fmaf_rn(ch0, (float)P.sv, -0.5f), P.sv, s0, s1, fs);
@@ -915,11 +932,11 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             }
             hit = col.w != 0.0f;
           } else {
-            hit = smk_classify<DT, 1>(P, ch0, ch1, ch2, ch3, col);
+            hit = smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col);
           }
           d_hit = hit;
           if (hit) {
-            if (Q.fast_tf) {
+            if (TF == 1 && Q.fast_tf) {
               col.x = slab_tex_chan(tx4, 0);
               col.y = slab_tex_chan(tx4, 1);
               col.z = slab_tex_chan(tx4, 2);
@@ -973,6 +990,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           n_hit += (float)__popcll(__ballot(d_hit));
           n_anyhit += __any(d_hit) ? 1.f : 0.f;
         }
+        }  // rep
       }
       if (lane == 0) lds_st(&ctl[8 + wave], SLAB_DONE);
       if (tracing && lane == 0) atomicAdd(Q.trace + 8 * (size_t)blockIdx.x + 7, (unsigned)n_it);
@@ -1000,7 +1018,12 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
     __syncthreads();
     if (tid == 0 && ctl[3]) *(volatile int *)Q.status = ctl[3];
   }
-  if (tid == 0 && Q.tile_ticks) Q.tile_ticks[tile] = max((unsigned)__builtin_amdgcn_s_memrealtime() - trace_t0, 1u);
+  if (tid == 0 && Q.tile_ticks) {
+    Q.tile_ticks[tile] = max((unsigned)__builtin_amdgcn_s_memrealtime() - trace_t0, 1u);
+    // (ctl[4] = loader 0's landed count, final after the barrier above; every loader streams every slice)
+    Q.tile_ticks[Q.ntiles + tile] = npos > 0 ? (unsigned)min(max(ctl[4], 0), npos + 1) : 0u;
+    Q.tile_ticks[2 * Q.ntiles + tile] = npos > 0 ? (unsigned)(npos + 1) : 0u;
+  }
   if (tracing && tid == 0) {
     unsigned *t = Q.trace + 8 * (size_t)blockIdx.x;
     t[0] = trace_t0;
@@ -1132,9 +1155,9 @@ bool slab_bundle_slice_range(const RenderParams &P, double fx0, double fy0, doub
 }
 }  // namespace
 
-template <int DT, int SH, int PERM, int NW, int NL, bool DIAG>
+template <int DT, int SH, int PERM, int NW, int NL, bool DIAG, int TF = 1>
 static hipError_t launch_slab(const RenderParams &P, const SlabParams &Q, size_t lds, int nblocks, hipStream_t s) {
-  auto k = smk_k_slab<DT, SH, PERM, NW, NL, DIAG>;
+  auto k = smk_k_slab<DT, SH, PERM, NW, NL, DIAG, TF>;
   static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -1148,12 +1171,15 @@ static hipError_t launch_slab(const RenderParams &P, const SlabParams &Q, size_t
 }
 
 // plan + launch; returns hipErrorNotSupported when the configuration must use the gather kernel
-hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T, int opt_tile, int forced,
-                           const void *const vox_by_perm[3], SlabAux *aux, const char **why, hipStream_t s) {
+hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kind, int opt_T, int opt_tile, int forced,
+                           const void *vox_native, const void *vox_xmajor, SlabAux *aux, const char **why,
+                           hipStream_t s) {
   const int opt_fly = (opt_T >> 8) & 0xff;  // (developer knobs travel packed: slab_T | slab_fly << 8 | slab_ns << 16)
   const int opt_ns = (opt_T >> 16) & 0xff;
   opt_T &= 0xff;
   *why = nullptr;
+  if (tf_mode != 1 && tf_mode != 2) { *why = "1-D colour table (scalar volumes: gather kernel)"; return hipErrorNotSupported; }
+  if (tf_mode == 2 && (!P.tf3d || P.s3v < 1 || P.s3g < 1 || P.s3h < 1)) { *why = "no 3-D table"; return hipErrorNotSupported; }
   if (P.pert_on) { *why = "perturbation"; return hipErrorNotSupported; }
   if (P.blend == SMK_BLEND_BACK_TO_FRONT) { *why = "back-to-front blend (slices stream front to back)"; return hipErrorNotSupported; }
   if (P.depth) { *why = "first-hit depth requested"; return hipErrorNotSupported; }  // (a register the fast path cannot spare)
@@ -1175,23 +1201,21 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
   if (as == 2) { Q.perm = 0; Q.au = 0; Q.av = 1; }
   else if (as == 1) { Q.perm = 1; Q.au = 0; Q.av = 2; }
   else { Q.perm = 2; Q.au = 1; Q.av = 2; }
-  if (Q.perm == 2 && !vox_by_perm[2]) { *why = "x-major copy unavailable"; return hipErrorNotSupported; }
-  if (Q.perm == 1 && !vox_by_perm[1]) { *why = "y-major copy unavailable"; return hipErrorNotSupported; }
+  if (Q.perm == 2 && !vox_xmajor) { *why = "x-major copy unavailable"; return hipErrorNotSupported; }
   Q.dir = Bc[as] > 0 ? 1 : -1;
   Q.Ou = P.O[Q.au]; Q.Ov = P.O[Q.av]; Q.Os = P.O[as];
   Q.Du = P.D[Q.au]; Q.Dv = P.D[Q.av]; Q.Ds = P.D[as];
-  const int swv = 1 << P.sw_log2;  // voxels per strip row
-  const int nsu = (Q.Du + swv - 1) / swv;
-  Q.DuPad = nsu * swv;
-  Q.stripStrideB = (unsigned)Q.Dv * 128u;
-  Q.strideSb = (long long)nsu * Q.Dv * 128;
-  Q.vox = vox_by_perm[Q.perm];
+  if (Q.perm == 0) { Q.strideV = P.D[0]; Q.strideS = (long long)P.D[0] * P.D[1]; Q.vox = vox_native; }
+  else if (Q.perm == 1) { Q.strideV = (long long)P.D[0] * P.D[1]; Q.strideS = P.D[0]; Q.vox = vox_native; }
+  else { Q.strideV = P.D[1]; Q.strideS = (long long)P.D[1] * P.D[2]; Q.vox = vox_xmajor; }  // [x][z][y]
   if (P.cplane_on) { *why = "free clip plane (a per-sample half-space test: gather kernel)"; return hipErrorNotSupported; }
   // an empty region (a clip plane outside a shard's box): the gather kernel's explicit comparisons
   // render it as nothing; the median-of-three membership test here needs lo <= hi
   for (int a = 0; a < 3; ++a)
     if (!(P.lo[a] <= P.hin[a])) { *why = "region is empty"; return hipErrorNotSupported; }
   if (Q.Ds > 4096) { *why = "more than 4096 slices"; return hipErrorNotSupported; }
+  // u8 voxels are 8 B: the DMA moves 16-B units, so rows must start and end on even voxels
+  if (dtype == 0 && ((Q.Du & 1) || (Q.strideV & 1) || (Q.strideS & 1))) { *why = "odd U extent for 8-byte voxels"; return hipErrorNotSupported; }
 
   // workgroup shape: consumer waves are 8x8 pixel sub-tiles; NL loader waves.
   //   light windows: 32x16 tile, 8+1 waves, two workgroups per CU
@@ -1279,16 +1303,8 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     const double span = P.N[as] <= 3 ? 3.0 : 2.5;
     int Wu = (int)ceil(max_eu + span * max_drift_u + 2 * SLAB_EPS) + 2;
     int Wv = (int)ceil(max_ev + span * max_drift_v + 2 * SLAB_EPS) + 2;
-    // windows start on half strips (4 units): up to hsw - 1 voxels of slack in front, whole half strips in all
-    const int hsw = swv / 2;
-    Wu = (Wu + (hsw - 1) + (hsw - 1)) / hsw * hsw;
-    // the flat image's pitch must repeat the lane pattern within 7 chunks: wp / gcd(64, wp) <= 7
-    for (;; Wu += hsw) {
-      int g = 64, r = Wu / upv;
-      while (r) { int t = g % r; g = r; r = t; }
-      if ((Wu / upv) / g <= 7) break;
-    }
-    Wu = std::min(Wu, Q.DuPad);
+    if (dtype == 0) Wu = ((Wu + 1) & ~1) + 2;  // even width, even alignment of the origin
+    Wu = std::min(Wu, Q.Du);
     Wv = std::min(Wv, Q.Dv);
     if (Wu < 2 || Wv < 2) { *why = "degenerate window"; return hipErrorNotSupported; }
     // fixed window shape: wu 16-byte units per row on an LDS pitch of the next multiple of 8 units
@@ -1298,7 +1314,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     Q.wv = Wv;
     if (Q.wu > 64) { if (ci + 1 < ncfg) continue; *why = "window wider than one DMA chunk"; return hipErrorNotSupported; }
     if (Q.Du > 2047 || Q.Dv > 2047) { *why = "stored box wider than 2047 voxels across the view"; return hipErrorNotSupported; }
-    Q.wp = Q.wu;  // a multiple of 4 units with wp / gcd(64, wp) <= 7 (or the whole padded stored extent)
+    Q.wp = (Q.wu + 7) & ~7;
     {
       int g = 64, r = Q.wp;
       while (r) { int t = g % r; g = r; r = t; }  // gcd(64, wp)
@@ -1316,10 +1332,10 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     // light enough for this configuration?  otherwise try the next (heavier-duty) one
     if (ci + 1 < ncfg && (double)Q.chunks * 1024.0 / (nw * 64) > 16.0 * nl) continue;
 
-    Q.use_ah = (P.third_axis && P.nelts <= 3 && P.sv >= 2 && P.sv <= 2048) ? 1 : 0;
-    if (P.sv < 2 || P.sg < 2) { *why = "transfer function smaller than 2x2"; return hipErrorNotSupported; }
-    const size_t occ_bytes = (size_t)P.occ_roww * P.sg * 4;
-    Q.fast_tf = (!P.third_axis || Q.use_ah) ? 1 : 0;
+    Q.use_ah = (tf_mode == 1 && P.third_axis && P.nelts <= 3 && P.sv >= 2 && P.sv <= 2048) ? 1 : 0;
+    if (tf_mode == 1 && (P.sv < 2 || P.sg < 2)) { *why = "transfer function smaller than 2x2"; return hipErrorNotSupported; }
+    const size_t occ_bytes = tf_mode == 1 ? (size_t)P.occ_roww * P.sg * 4 : 0;
+    Q.fast_tf = (tf_mode == 1 && (!P.third_axis || Q.use_ah)) ? 1 : 0;
     // (measured: 5.99 -> 5.61 ms on 1024^3, where the texel gathers share the texture path with a
     //  heavy stream; no gain at 512^3, where the 8 KB are worth more as ring slots)
     Q.use_occ = (Q.fast_tf && Q.mask_need && P.tf_occ && occ_bytes > 0 && occ_bytes <= 8192) ? 1 : 0;
@@ -1409,7 +1425,9 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
         aux->d_ticks = nullptr;
         aux->h_ticks = nullptr;
         aux->ticks_cap = 0;
-        hipError_t e = hipMalloc((void **)&aux->d_ticks, (size_t)nt * 4);
+        hipError_t e = hipMalloc((void **)&aux->d_ticks, (size_t)nt * 12);
+        if (e != hipSuccess) return e;
+        e = hipMemset(aux->d_ticks, 0, (size_t)nt * 12);
         if (e != hipSuccess) return e;
         e = hipHostMalloc((void **)&aux->h_ticks, (size_t)nt * 4, hipHostMallocDefault);
         if (e != hipSuccess) return e;
@@ -1420,6 +1438,8 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
         if (e != hipSuccess) return e;
       }
       Q.tile_ticks = aux->d_ticks;
+      Q.ntiles = nt;
+      aux->ticks_n_last = nt;
       ticks_sig_now = tsig;
       ticks_n_now = nt;
       const int slots = nw + nl;  // (part of the cached plan's key)
@@ -1554,12 +1574,23 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int shade_kind, int opt_T,
     };
 #define GO(D, S, R, N, L)                                                                              \
   if (dtype == D && shade_kind == S && Q.perm == R && nw == N && nl == L) {                          \
+    if (tf_mode == 2) {                                                                              \
+      if constexpr ((N == 8 && L == 2) || (N == 12 && L == 4))                                       \
+        return after_launch(launch_slab<D, S, R, N, L, false, 2>(P, Q, lds, nblocks, s));            \
+      *why = "no dense-3-D-table instance for this tile size";                                       \
+      return hipErrorNotSupported;                                                                   \
+    }                                                                                                \
     if constexpr (D == 1 && S == 1) {                                                                \
       if (diag) return after_launch(launch_slab<D, S, R, N, L, true>(P, Q, lds, nblocks, s));        \
     }                                                                                                \
     return after_launch(launch_slab<D, S, R, N, L, false>(P, Q, lds, nblocks, s));                   \
   }
+  // product tile shapes: 32x16 px with 8+2 waves, 32x24 px with 12+4; the others are experiment knobs (option "tile")
+#ifdef SLAB_ALL_TILES
 #define GO_NW(D, S, R) GO(D, S, R, 4, 1) GO(D, S, R, 6, 2) GO(D, S, R, 8, 1) GO(D, S, R, 8, 2) GO(D, S, R, 8, 4) GO(D, S, R, 9, 2) GO(D, S, R, 12, 2) GO(D, S, R, 12, 4)
+#else
+#define GO_NW(D, S, R) GO(D, S, R, 8, 2) GO(D, S, R, 12, 4)
+#endif
 #define GO_R(D, S) GO_NW(D, S, 0) GO_NW(D, S, 1) GO_NW(D, S, 2)
 #ifdef SLAB_FEW_INSTANCES
     GO_R(1, 1)

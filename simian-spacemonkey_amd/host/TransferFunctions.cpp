@@ -5,6 +5,8 @@
 
 #include <cmath>
 #include <cstddef>
+#include <algorithm>
+#include <cstring>
 
 namespace smktf {
 namespace {
@@ -193,6 +195,203 @@ void rasterize_vgh(unsigned char *ptex, int sx, int sy, float slider1hi) {
   m = -m;
   for (int i = 0; i < sy; ++i)
     for (int j = 1; j <= cent; ++j) ptex[((size_t)i * sx + j + cent) * 4 + 3] = to_byte(clamp255(j * m + b));
+}
+
+// ------------------------------------------------------------------------------------ probe
+
+void probe_world_to_volume(const float pos[3], const float trans[3], const float xform[16], float scale, const float fsize[3], float vpos[3]) {
+  // volm = T(trans) * xform * S(scale) * T(-size/2) * S(size)   (DPWidgetRen.cpp:281-306; matrixMult VectorMath.h:424-445)
+  auto mul = [](float o[16], const float a[16], const float b[16]) {
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 4; ++r) o[c * 4 + r] = a[r] * b[c * 4] + a[4 + r] * b[c * 4 + 1] + a[8 + r] * b[c * 4 + 2] + a[12 + r] * b[c * 4 + 3];
+  };
+  auto ident = [](float m[16]) {
+    memset(m, 0, 16 * sizeof(float));
+    m[0] = m[5] = m[10] = m[15] = 1;
+  };
+  float m1[16], m2[16], sc[16], m3[16], m4[16], m5[16], volm[16];
+  ident(m1);
+  m1[12] = trans[0]; m1[13] = trans[1]; m1[14] = trans[2];
+  mul(m2, m1, xform);
+  ident(sc);
+  sc[0] = sc[5] = sc[10] = scale;
+  mul(m3, m2, sc);
+  ident(m4);
+  m4[12] = (float)(-.5 * fsize[0]); m4[13] = (float)(-.5 * fsize[1]); m4[14] = (float)(-.5 * fsize[2]);
+  mul(m5, m3, m4);
+  float m6[16];
+  ident(m6);
+  m6[0] = fsize[0]; m6[5] = fsize[1]; m6[10] = fsize[2];
+  mul(volm, m5, m6);
+  // affine inverse (VolumeRenderer::inverseMatrix's formula, VectorMath.h inverseMatrix), double inside
+  const float *m = volm;
+  const double det = (double)m[0] * m[5] * m[10] - (double)m[0] * m[6] * m[9] - (double)m[1] * m[4] * m[10] + (double)m[1] * m[6] * m[8] +
+                     (double)m[2] * m[4] * m[9] - (double)m[2] * m[5] * m[8];
+  double inv[16];
+  inv[0] = ((double)m[5] * m[10] - (double)m[6] * m[9]) / det;
+  inv[1] = (-(double)m[1] * m[10] + (double)m[2] * m[9]) / det;
+  inv[2] = ((double)m[1] * m[6] - (double)m[2] * m[5]) / det;
+  inv[4] = (-(double)m[4] * m[10] + (double)m[6] * m[8]) / det;
+  inv[5] = ((double)m[0] * m[10] - (double)m[2] * m[8]) / det;
+  inv[6] = (-(double)m[0] * m[6] + (double)m[2] * m[4]) / det;
+  inv[8] = ((double)m[4] * m[9] - (double)m[5] * m[8]) / det;
+  inv[9] = (-(double)m[0] * m[9] + (double)m[1] * m[8]) / det;
+  inv[10] = ((double)m[0] * m[5] - (double)m[1] * m[4]) / det;
+  inv[12] = -(inv[0] * m[12] + inv[4] * m[13] + inv[8] * m[14]);
+  inv[13] = -(inv[1] * m[12] + inv[5] * m[13] + inv[9] * m[14]);
+  inv[14] = -(inv[2] * m[12] + inv[6] * m[13] + inv[10] * m[14]);
+  for (int a = 0; a < 3; ++a) vpos[a] = (float)(inv[a] * pos[0] + inv[4 + a] * pos[1] + inv[8 + a] * pos[2] + inv[12 + a]);
+}
+
+void probe_sample(const unsigned char *dp, int ne, int sx, int sy, int sz, int dmode, const float vpos[3], ProbeSample *out) {
+  ProbeSample &s = *out;
+  const int px = (int)(vpos[0] * sx), py = (int)(vpos[1] * sy), pz = (int)(vpos[2] * sz);
+  const float fpos[3] = {vpos[0] * sx, vpos[1] * sy, vpos[2] * sz};
+  s.cell[0] = px; s.cell[1] = py; s.cell[2] = pz;
+  memset(s.corners, 0, sizeof s.corners);
+  memset(s.hessian_pos, 0, sizeof s.hessian_pos);
+  s.value[0] = s.value[1] = s.value[2] = 0;
+  s.inside = !((px < 1) || (px > (sx - 2)) || (py < 1) || (py > (sy - 2)) || (pz < 1) || (pz > (sz - 2)));
+  if (!s.inside) return;
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int k = 0; k < 2; ++k) {
+        const unsigned char *v = dp + ((size_t)(pz + i) * sx * sy * ne) + ((size_t)(py + j) * sx * ne) + ((size_t)(px + k) * ne);
+        float *c = s.corners[i * 4 + j * 2 + k];
+        switch (dmode) {
+          case DM_V1:
+            c[0] = (float)(v[0] / 255.0);
+            break;
+          case DM_V1G: case DM_V2: case DM_V2G:
+            c[0] = (float)(v[0] / 255.0);
+            c[1] = (float)(v[1] / 255.0);
+            break;
+          case DM_V2GH: case DM_V3: case DM_V3G: case DM_V4:  // (falls through into the VGH case in the reference)
+          case DM_VGH: case DM_V1GH: case DM_VGH_VG: case DM_VGH_V: {
+            c[0] = (float)(v[0] / 255.0);
+            c[1] = (float)(v[1] / 255.0);
+            float h = (float)(v[2] / 85.0 - 1);
+            h = h > 0 ? (float)sqrt(h) : (float)-sqrt(-h);
+            s.hessian_pos[i * 4 + j * 2 + k] = (float)((h + 1) / 2.0);
+            c[2] = (float)(v[2] / 169.0);
+            break;
+          }
+          default: break;
+        }
+      }
+  // triLerpV3 (:600-621): fractions of the floating-point position, x then y then z
+  const float fx = fpos[0] - (int)fpos[0], fy = fpos[1] - (int)fpos[1], fz = fpos[2] - (int)fpos[2];
+  for (int e = 0; e < 3; ++e) {
+    const float x1 = s.corners[0][e] + (float)(s.corners[1][e] - s.corners[0][e]) * fx;
+    const float x2 = s.corners[2][e] + (float)(s.corners[3][e] - s.corners[2][e]) * fx;
+    const float x3 = s.corners[4][e] + (float)(s.corners[5][e] - s.corners[4][e]) * fx;
+    const float x4 = s.corners[6][e] + (float)(s.corners[7][e] - s.corners[6][e]) * fx;
+    const float xy1 = x1 + (x2 - x1) * fy, xy2 = x3 + (x4 - x3) * fy;
+    s.value[e] = (xy1 + (xy2 - xy1) * fz);
+  }
+}
+
+void place_brush(LevWidgetState *brush, Brush kind, int dmode, const ProbeSample &s, float slider) {
+  if (!s.inside) {  // outside: the brush collapses into the origin (:348-352)
+    const float z[2] = {0, 0};
+    set_positions(brush, z, z, z);
+    return;
+  }
+  const float *val = s.value;
+  auto maxf = [](float a, float b) { return a > b ? a : b; };
+  auto minf = [](float a, float b) { return a < b ? a : b; };
+  if (kind == EllipseBrush) {
+    const float bsz = (float)((1.0 - slider) / 4.0);
+    const float l[2] = {val[0] - bsz, val[1] + bsz}, r[2] = {val[0] + bsz, val[1] + bsz}, b[2] = {val[0] + bsz, val[1] - bsz};
+    set_positions(brush, b, l, r, val[0], val[1]);
+    brush->type = LWsquare;
+  } else if (kind == TriangleBrush || kind == AutoEllipseBrush) {
+    float maxx = -1000, maxy = -1000, minx = 1000, miny = 1000;
+    for (int i = 0; i < 8; ++i) {
+      maxx = maxf(maxx, s.corners[i][0]); maxy = maxf(maxy, s.corners[i][1]);
+      minx = minf(minx, s.corners[i][0]); miny = minf(miny, s.corners[i][1]);
+    }
+    const float bsz = (float)((1.0 - slider) * 2);
+    const float w = (float)(((maxx - minx) / 2.0) > .01 ? ((maxx - minx) / 2.0) : .01);
+    const float h = (float)(((maxy - miny) / 2.0) > .01 ? ((maxy - miny) / 2.0) : .01);
+    const float l[2] = {val[0] - w * bsz, val[1] + h * bsz}, r[2] = {val[0] + w * bsz, val[1] + h * bsz};
+    float b[2] = {val[0], 0};
+    if (kind == TriangleBrush) {
+      set_positions(brush, b, l, r, 0, val[1] - h * bsz);
+      brush->type = LWtriangle;
+    } else {
+      b[0] = val[0] + w * bsz;
+      b[1] = val[1] - h * bsz;
+      set_positions(brush, b, l, r, val[0], val[1]);
+      brush->type = LWsquare;
+    }
+  }
+  if (dmode == DM_V1 || dmode == DM_VGH_V || kind == OneDBrush || kind == AutoOneDBrush) {
+    float maxx = -1000, minx = 1000;
+    for (int i = 0; i < 8; ++i) {
+      maxx = maxf(maxx, s.corners[i][0]);
+      minx = minf(minx, s.corners[i][0]);
+    }
+    const float bsz = (float)((1.0 - slider) * 2);
+    const float w = (float)(((maxx - minx) / 2.0) > .01 ? ((maxx - minx) / 2.0) : .01);
+    float l[2] = {val[0] - w * bsz, 1}, r[2] = {val[0] + w * bsz, 1};
+    const float b[2] = {val[0], 0};
+    if (kind == OneDBrush) {
+      l[0] = (float)(val[0] + (1.0 - slider) / 4.0);
+      r[0] = (float)(val[0] - (1.0 - slider) / 4.0);
+    }
+    set_positions(brush, b, l, r, val[0], val[1]);
+    brush->type = LW1d;
+  }
+}
+
+// ------------------------------------------------------------------------------------ frame
+
+TFFrame::TFFrame(int sv_, int sg_, int sh_, int dmode_) : sv(sv_), sg(sg_), sh(sh_), dmode(dmode_), paintex((size_t)sv_ * sg_ * sh_ * 4, 0) {
+  // TFWidgetRen::init (:648-656): position of the root widget, alpha .7, ellipse
+  const float b[2] = {.5f, 0}, l[2] = {.3f, .7f}, r[2] = {.7f, .7f};
+  set_positions(&brush, b, l, r);
+  brush.alpha = .7f;
+  brush.type = LWsquare;
+}
+
+void TFFrame::clear_paint() { std::fill(paintex.begin(), paintex.end(), (unsigned char)0); }
+
+namespace {
+// LevWidget::rasterize's head (:677-682): scalar data modes turn every widget into the 1-D style over the full height
+LevWidgetState for_mode(LevWidgetState w, int dmode, bool faux) {
+  if (dmode == DM_V1 || dmode == DM_VGH_V) {
+    w.bottom[1] = 0;
+    w.left[1] = 1;
+    w.right[1] = 1;
+    w.type = LW1d;
+  }
+  w.faux_shading = faux;
+  return w;
+}
+}  // namespace
+
+void TFFrame::paint() {
+  switch (brush_kind) {
+    case EllipseBrush: case AutoEllipseBrush: case OneDBrush: case AutoOneDBrush:
+      rasterize(for_mode(brush, dmode, faux_shading), paintex.data(), sv, sg, sh);
+      break;
+    case TriangleBrush:
+      widgets.insert(widgets.begin(), brush);
+      break;
+    default: break;
+  }
+}
+
+void TFFrame::drop() { widgets.insert(widgets.begin(), brush); }
+
+void TFFrame::regenerate(unsigned char *deptex, unsigned char *deptex3) const {
+  const size_t n = (size_t)sv * sg * sh * 4;
+  if (deptex3) memset(deptex3, 0, n);
+  memcpy(deptex, paintex.data(), n);
+  // the list is root -> newest -> ... -> oldest and every widget rasterises its successors before itself
+  for (size_t k = widgets.size(); k-- > 0;) rasterize(for_mode(widgets[k], dmode, faux_shading), deptex, sv, sg, sh);
+  if (brushon) rasterize(for_mode(brush, dmode, faux_shading), deptex, sv, sg, sh);
 }
 
 }  // namespace smktf

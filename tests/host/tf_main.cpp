@@ -1,14 +1,95 @@
 // tf_main.cpp -- drives simian-spacemonkey_amd/host/TransferFunctions.{h,cpp} for tests/test_transfer_functions.py
 //   tf_main lev <shape 0..3> <faux 0|1> <sv> <sg> <sh> bx by lx ly rx ry tw th H S L alpha be <in.tex|-> <out.tex>
 //   tf_main vgh <sx> <sy> <slider1hi> <out.tex>
+//   tf_main session <script>     a TF-window session without the window: one command per line
+//        frame sv sg sh dmode faux | volume file sx sy sz nelts | widget shape bx by lx ly rx ry tw th H S L alpha be
+//        brush kind on | probe vx vy vz slider | world px py pz tx ty tz scale fx fy fz m0..m15 | paint | drop | clear | regen out.tex
+//      "probe" prints: inside cx cy cz v0 v1 v2 ; "world" prints: vx vy vz (%.9g)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
+#include <memory>
+#include <sstream>
+#include <string>
 #include <vector>
 
 #include "TransferFunctions.h"
 
+static int session(const char *path) {
+  std::ifstream in(path);
+  if (!in) return 3;
+  std::unique_ptr<smktf::TFFrame> fr;
+  std::vector<unsigned char> vol;
+  int vx = 0, vy = 0, vz = 0, vne = 1;
+  std::string line;
+  while (std::getline(in, line)) {
+    std::istringstream ss(line);
+    std::string cmd;
+    if (!(ss >> cmd)) continue;
+    if (cmd == "frame") {
+      int sv, sg, sh, dm, faux;
+      ss >> sv >> sg >> sh >> dm >> faux;
+      fr.reset(new smktf::TFFrame(sv, sg, sh, dm));
+      fr->faux_shading = faux != 0;
+    } else if (cmd == "volume") {
+      std::string f;
+      ss >> f >> vx >> vy >> vz >> vne;
+      vol.resize((size_t)vx * vy * vz * vne);
+      FILE *fp = fopen(f.c_str(), "rb");
+      if (!fp || fread(vol.data(), 1, vol.size(), fp) != vol.size()) return 3;
+      fclose(fp);
+    } else if (cmd == "widget" && fr) {
+      smktf::LevWidgetState w;
+      int shape;
+      float b[2], l[2], r[2], tw, th, H, S, L;
+      ss >> shape >> b[0] >> b[1] >> l[0] >> l[1] >> r[0] >> r[1] >> tw >> th >> H >> S >> L >> w.alpha >> w.boundary_emphasis;
+      w.type = (smktf::WidgetShape)shape;
+      smktf::set_positions(&w, b, l, r, tw, th);
+      smktf::hsl_to_rgb(H, S, L, w.color);
+      fr->widgets.insert(fr->widgets.begin(), w);
+    } else if (cmd == "brush" && fr) {
+      int kind, on;
+      ss >> kind >> on;
+      fr->brush_kind = (smktf::Brush)kind;
+      fr->brushon = on != 0;
+    } else if (cmd == "probe" && fr) {
+      float v[3], slider;
+      ss >> v[0] >> v[1] >> v[2] >> slider;
+      smktf::ProbeSample s;
+      smktf::probe_sample(vol.data(), vne, vx, vy, vz, fr->dmode, v, &s);
+      if (fr->brushon || !s.inside) smktf::place_brush(&fr->brush, fr->brush_kind, fr->dmode, s, slider);
+      printf("%d %d %d %d %.9g %.9g %.9g\n", (int)s.inside, s.cell[0], s.cell[1], s.cell[2], s.value[0], s.value[1], s.value[2]);
+    } else if (cmd == "world") {
+      float p[3], t[3], scale, fs[3], m[16], out[3];
+      ss >> p[0] >> p[1] >> p[2] >> t[0] >> t[1] >> t[2] >> scale >> fs[0] >> fs[1] >> fs[2];
+      for (float &x : m) ss >> x;
+      smktf::probe_world_to_volume(p, t, m, scale, fs, out);
+      printf("%.9g %.9g %.9g\n", out[0], out[1], out[2]);
+    } else if (cmd == "paint" && fr) fr->paint();
+    else if (cmd == "drop" && fr) fr->drop();
+    else if (cmd == "clear" && fr) fr->clear_paint();
+    else if (cmd == "regen" && fr) {
+      std::string f;
+      ss >> f;
+      std::vector<unsigned char> dep(fr->paintex.size()), dep3(fr->paintex.size(), 7);
+      fr->regenerate(dep.data(), dep3.data());
+      for (unsigned char c : dep3)
+        if (c) return 4;  // deptex3 is cleared
+      FILE *fp = fopen(f.c_str(), "wb");
+      if (!fp) return 3;
+      fwrite(dep.data(), 1, dep.size(), fp);
+      fclose(fp);
+    } else {
+      fprintf(stderr, "session: bad line '%s'\n", line.c_str());
+      return 2;
+    }
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc == 3 && !strcmp(argv[1], "session")) return session(argv[2]);
   if (argc >= 6 && !strcmp(argv[1], "vgh")) {
     const int sx = atoi(argv[2]), sy = atoi(argv[3]);
     std::vector<unsigned char> t((size_t)sx * sy * 4, 0);

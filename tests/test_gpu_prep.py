@@ -188,3 +188,20 @@ def test_merge_fields_bit_exact(R, O, nf, dims):
     assert ref[..., nf].max() == 255
     assert np.array_equal(out.cpu().numpy(), ref)
     assert np.array_equal(nrm.cpu().numpy(), refn)
+
+
+@pytest.mark.parametrize("dims,seed", [((64, 64, 64), 1), ((40, 24, 33), 2)])
+def test_genvol_spheres_on_the_gpu_bit_exact(R, O, dims, seed):
+    """The product's test-volume generator (smk_synth_volume_device kind 1 = `genvol -spheres 4 -p 10
+    -pscale .7 -pwrap 3 3 3 -pabs -blur -bw 1 1 1 .7`, genvol/main.cpp:212-256, 334-430 + perlin.c) against
+    the CPU checker's restatement, whose Perlin noise is pinned against the reference's own perlin.c
+    (tests/test_perlin_ref.py): every byte equal, double-precision noise and float blur sums included.
+    This is the volume bench.py and the full-size tests render."""
+    import torch
+    sx, sy, sz = dims
+    out = torch.zeros((sz, sy, sx), dtype=torch.uint8, device="cuda")
+    R.synth_volume_device(1, seed, dims, out.data_ptr())
+    ref = O.genvol_spheres(dims, seed=seed)
+    got = out.cpu().numpy()
+    assert ref.max() > 150 and len(np.unique(ref)) > 8
+    assert np.array_equal(got, ref), "differs in %d voxels" % int((got != ref).sum())

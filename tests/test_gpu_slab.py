@@ -40,9 +40,11 @@ def test_every_axis_and_direction(R, pose, f32):
     assert np.abs(b - ref).max() <= TOL
 
 
-@pytest.mark.parametrize("kind,shade", [("cfg2", 0), ("cfg3", 1), ("cfg3", 2), ("cfg4", 0)])
-def test_modes(R, kind, shade):
-    sc = make_scene(kind, n=32, size=64, steps=64, pose="diag", f32=True, shade=shade)
+@pytest.mark.parametrize("kind,shade,f32", [("cfg2", 0, True), ("cfg3", 1, True), ("cfg3", 2, True), ("cfg4", 0, True),
+                                             ("tf3d", 1, True), ("tf3d", 0, False), ("tf3d", 2, False)])
+def test_modes(R, kind, shade, f32):
+    """2-D table, 2-D x third axis, and the dense 3-D (v,g,h) table of BASELINE configs 4/5 on the slice-ring kernel"""
+    sc = make_scene(kind, n=32, size=64, steps=64, pose="diag", f32=f32, shade=shade)
     ref = sc.render()
     a, b = _both(R, sc)
     assert np.array_equal(a, b)
@@ -139,7 +141,7 @@ def test_sharded_regions(gpu_renderer_factory, smk, world):
 
 
 def test_forced_slab_reports_why_it_cannot_run(R, smk):
-    sc = make_scene("tf3d", f32=True)
+    sc = make_scene("cfg1")          # scalar volume, 1-D colour table: the gather kernel's alone
     push_scene(R, sc)
     R.set_option("kernel", 2)
     with pytest.raises(smk.SmkError, match="gather-only|not applicable"):

@@ -10,12 +10,16 @@ from _scenes import make_scene, push_scene
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("world,size", [(2, 48), (4, 48), (8, 48), (8, 45)])
 @pytest.mark.parametrize("pose", ["rot", "back"])
-def test_sharded_frames_composite_to_whole(gpu_renderer_factory, smk, world, pose):
+def test_sharded_frames_composite_to_whole(gpu_renderer_factory, smk, world, size, pose, kernel):
+    """(size 45, pose "back": the centre row of an odd viewport under a rotation about y runs exactly ALONG
+    the shard boundary y = N/2 -- fma(m, B, A) rounds onto the face for every plane while (lo - A) / B says the
+    ray leaves at once; both kernels bracketed that ray's plane range too tightly until round 2)"""
     import torch
     from simian_spacemonkey_amd import sortlast
-    sc = make_scene("cfg3", n=32, size=48, steps=48, pose=pose, f32=True, shade=1)
+    sc = make_scene("cfg3", n=32, size=size, steps=48, pose=pose, f32=True, shade=1)
     ref = sc.render()
     npix = sc.width * sc.height
     layers = torch.zeros((world, npix, 4), dtype=torch.float32, device="cuda")
@@ -26,6 +30,7 @@ def test_sharded_frames_composite_to_whole(gpu_renderer_factory, smk, world, pos
             rs.append(R)
             R.set_shard(r, world)
             push_scene(R, sc)
+            R.set_option("kernel", kernel)      # 0: auto (the first frame of a configuration = slice-ring kernel), 1: gather
             R.render_device(layers[r].data_ptr(), None, None)
         torch.cuda.synchronize()
         for R in rs:   # asynchronous frames report kernel-side failures through the status word

@@ -26,12 +26,13 @@ def main():
     ap.add_argument("--workload", default="cfg4")
     ap.add_argument("--pose", default="rot")
     ap.add_argument("--u8", action="store_true")
+    ap.add_argument("--synth", type=int, default=1, help="1 genvol spheres (bench input), 0 round 1's smooth shells")
     ap.add_argument("--variants", nargs="*", default=["kernel=1"])
     a = ap.parse_args()
     pkg = bench.load_package()
     r = pkg.Renderer(0)
     n = a.volume
-    vghf, nrm = bench.make_volume(r, n)
+    vghf, nrm = bench.make_volume(r, n, kind=a.synth)
     if a.u8:
         v8 = (vghf * 255.0).to(torch.uint8)
         r.upload_volume_device(v8.data_ptr(), (n, n, n), 3, 0, nrm.data_ptr())
