@@ -47,6 +47,46 @@ def pmc_traffic(workload):
     return t.get(workload, {}).get("hbm_bytes_per_launch")
 
 
+def pmc_insts(workload):
+    """Per-launch instruction counters of the ray-march kernel from the committed SQ passes
+    (profiles/rNN_pmc_sq_<cfg3|ns>.txt, written by tools/profile_round.sh + tools/pmc_summary.py)."""
+    d = os.path.join(ROOT, "profiles")
+    suffix = "_pmc_sq_%s.txt" % ("cfg3" if workload == "cfg3" else "ns")
+    paths = sorted(p for p in os.listdir(d) if p.endswith(suffix)) if os.path.isdir(d) else []
+    if not paths:
+        return None
+    out = {}
+    with open(os.path.join(d, paths[-1])) as f:
+        for line in f:
+            w = line.split()
+            if len(w) >= 5 and w[0].startswith("SQ_") and w[-2] == "mean":
+                out[w[0]] = float(w[-1])
+    out["file"] = "profiles/" + paths[-1]
+    return out
+
+
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0   # wave64 VALU instructions/ns the chip can issue: 256 CUs x 4 SIMDs, one per 4 cycles at 2.4 GHz
+
+
+def roofline_valu(kms, workload):
+    """Second roofline of the 512^3 frame: it is bound by vector-instruction issue, not by HBM.  achieved =
+    wave-level VALU instructions per launch (SQ_INSTS_VALU of the committed PMC pass of this kernel on this
+    input) over the kernel time measured live; peak = one VALU instruction per SIMD every 4 cycles."""
+    c = pmc_insts(workload)
+    if not c or "SQ_INSTS_VALU" not in c or kms <= 0:
+        return None
+    ach = c["SQ_INSTS_VALU"] / (kms * 1e-3) / 1e9
+    out = {"bound": "valu", "achieved": ach, "peak": VALU_PEAK_GINST, "unit": "Gwave-inst/s", "frac": ach / VALU_PEAK_GINST,
+           "valu_insts_per_launch": c["SQ_INSTS_VALU"], "salu_insts_per_launch": c.get("SQ_INSTS_SALU"),
+           "lds_insts_per_launch": c.get("SQ_INSTS_LDS"), "kernel_ms": kms, "source": c["file"],
+           "note": "packed-fp32 instructions (v_pk_fma_f32) count once but occupy the SIMD twice as long (tools/valu_probe.hip)"}
+    if c.get("SQ_INSTS_SALU") is not None:
+        out["salu_per_valu"] = c["SQ_INSTS_SALU"] / c["SQ_INSTS_VALU"]
+    if c.get("SQ_LDS_BANK_CONFLICT") is not None and c.get("SQ_LDS_IDX_ACTIVE"):
+        out["lds_bank_conflict_share"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_LDS_IDX_ACTIVE"]
+    return out
+
+
 def load_package():
     name = "simian_spacemonkey_amd"
     if name in sys.modules:
@@ -193,7 +233,10 @@ def roofline(r, kms, alg_bytes, size, note=None, traffic=None):
     ach = net / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
     out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
            "frac_of_achievable_6300": ach / 6300.0,   # float4-copy ceiling measured on MI355X (MI355X_MICROARCH.md, HBM)
-           "traffic": traffic, "kernel_ms": kms,
+           "traffic": traffic,
+           "traffic_source": "committed profiles/*_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+                             "on this code (counters cannot be read in-process)" if traffic is not None else None,
+           "kernel_ms": kms,
            "algorithmic_bytes_per_launch": net, "algorithmic_bytes_if_every_slice_streamed": alg_bytes,
            "slices_streamed_fraction": streamed}
     if note:
@@ -236,10 +279,12 @@ def extra_legs(r, frame, work, steps):
     out = {}
     K = max(3, min(steps, 8))
 
-    def run(name, size, planes, describe):
+    def run(name, size, planes, describe, kernel_opt=0):
         fr = frame[:size * size]
+        r.set_option("kernel", kernel_opt)
         with torch.cuda.stream(work):
             t, kms, kn = timed(r, K, 1, fr, 1, None)
+        r.set_option("kernel", 0)
         kernel, _, alg = r.last_frame_info()
         out[name] = {"workload": describe, "ms_per_frame": t / K * 1e3, "Msamples_per_s": float(size) * size * planes / (t / K) / 1e6,
                      "kernel": {1: "gather", 2: "slab-staged"}.get(kernel, str(kernel)),
@@ -274,8 +319,22 @@ def extra_legs(r, frame, work, steps):
     opaque[..., 3] = 255
     opaque[..., :3] = np.maximum(opaque[..., :3], 64)
     r.set_tf2d(opaque, None)
-    run("opaque_tf", 1024, 512, "cfg3's volume and camera with an OPAQUE table (alpha 255 everywhere): the bytes counted are those of "
-        "the slices really streamed")
+    # (slice-ring kernel forced: its loaders count what they stream; in auto mode the gather kernel wins this
+    #  frame -- a ray is over after a few samples -- and reads a fraction of the volume nobody counts)
+    run("opaque_tf", 1024, 512, "cfg3's volume and camera with an OPAQUE table (alpha 255 everywhere), slice-ring kernel: the bytes "
+        "counted are those of the slices really streamed", kernel_opt=2)
+    run("opaque_tf_auto", 1024, 512, "the same frame in auto mode (whichever kernel measured faster); no byte count for the gather kernel")
+    if out["opaque_tf_auto"]["kernel"] == "gather":
+        out["opaque_tf_auto"]["roofline"] = None
+    # continuity with round 1: the north-star frame on round 1's input (smooth noisy shells, whose rays saturate
+    # earlier: whole tiles stop streaming, which round 1's byte count ignored)
+    n1 = 1024
+    vghf, nrm = make_volume(r, n1, kind=0)
+    r.upload_volume_device(vghf.data_ptr(), (n1, n1, n1), 3, 1, nrm.data_ptr())
+    del vghf, nrm
+    torch.cuda.empty_cache()
+    configure(r, "cfg4", n1, 1024, 512)
+    run("north_star_on_round1_input", 1024, 512, "the north-star frame on round 1's synthetic volume (smk_synth_volume_device kind 0)")
     # BASELINE config 5 on one GPU: two 512^3 fields merged on the GPU (mergeMV + addG), dense 3-D table,
     # noise-perturbed fetch (createNoiseTex's texture, gluvvui's default weights (.2, 0) would displace by 51
     # voxels: SURVEY 8d's (.2, .1) scaled to the volume, see DESIGN), 1024^2 x 1024
@@ -504,6 +563,8 @@ def main():
                                         "(BASELINE.md sec. 2), see north_star" % n,
                                    traffic=pmc_traffic("cfg3") if default_workload and world == 1 else None)
         out["roofline"]["kernel_frames_timed"] = kn
+        if default_workload and world == 1:
+            out["roofline_valu"] = roofline_valu(kms, "cfg3")
     failures = int(r.stat("slab_failures"))
     if world > 1:
         out["rccl_ranks"] = 0 if rehearse else world

@@ -672,6 +672,7 @@ extern "C" int smk_set_option(smk_ctx *c, const char *key, int value) {
   else if (!strcmp(key, "slab_T")) c->opt_slab_T = value;
   else if (!strcmp(key, "inject_slab_status")) c->opt_inject_status = value;
   else if (!strcmp(key, "slab_fly")) c->opt_slab_fly = value < 0 ? 0 : (value > 63 ? 63 : value);
+  else if (!strcmp(key, "slab_sched")) c->opt_slab_sched = value < 0 ? 0 : (value > 15 ? 15 : value);
   else if (!strcmp(key, "slab_ns")) c->opt_slab_ns = value < 0 ? 0 : (value > 63 ? 63 : value);
   else if (!strcmp(key, "tile")) c->opt_tile = value;
   else if (!strcmp(key, "wave_w")) {
@@ -1055,7 +1056,7 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
     const char *why = nullptr;
     const int forced = c->opt_kernel == 2;
     c->slab.frame_ev0 = c->ev0;
-    const int knobs = c->opt_slab_T | (c->opt_slab_fly << 8) | (c->opt_slab_ns << 16);
+    const int knobs = c->opt_slab_T | (c->opt_slab_fly << 8) | (c->opt_slab_ns << 16) | (c->opt_slab_sched << 24);
     hipError_t e = smk_launch_slab(P, c->dtype, c->tf_mode, shade_kind_of(c), knobs, c->opt_tile, forced, c->d_vox, c->d_vox_x, &c->slab, &why, s);
     if (e == hipErrorNotSupported && why && !strcmp(why, "x-major copy unavailable")) {
       if (make_xmajor_copy(c)) return 1;

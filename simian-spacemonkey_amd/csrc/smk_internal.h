@@ -165,6 +165,7 @@ struct smk_ctx {
   int opt_kernel = 0, opt_slab_T = 0, opt_tf_raw = 0, opt_tile = 0;
   int opt_slab_fly = 0;  // slices a loader keeps in flight (0 = default)
   int opt_slab_ns = 0;   // cap on the ring's slots (0 = as many as fit)
+  int opt_slab_sched = 0;  // order of an XCD's tiles: 0 longest first, 1.. coarse weight classes + spatial blocks
   int opt_inject_status = 0;  // (test hook) the next slice-ring frame reports this status word
   int opt_wave_w = 8, opt_blk_w = 2, opt_lockstep = 1;
   SlabAux slab;  // slice-ring kernel side buffers

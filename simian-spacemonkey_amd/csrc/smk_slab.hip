@@ -1174,8 +1174,9 @@ static hipError_t launch_slab(const RenderParams &P, const SlabParams &Q, size_t
 hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kind, int opt_T, int opt_tile, int forced,
                            const void *vox_native, const void *vox_xmajor, SlabAux *aux, const char **why,
                            hipStream_t s) {
-  const int opt_fly = (opt_T >> 8) & 0xff;  // (developer knobs travel packed: slab_T | slab_fly << 8 | slab_ns << 16)
+  const int opt_fly = (opt_T >> 8) & 0xff;  // (developer knobs travel packed: slab_T | slab_fly << 8 | slab_ns << 16 | slab_sched << 24)
   const int opt_ns = (opt_T >> 16) & 0xff;
+  const int opt_sched = (opt_T >> 24) & 0xf;  // (experiment knob: order of an XCD's tiles, see the schedule)
   opt_T &= 0xff;
   *why = nullptr;
   if (tf_mode != 1 && tf_mode != 2) { *why = "1-D colour table (scalar volumes: gather kernel)"; return hipErrorNotSupported; }
@@ -1442,7 +1443,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
       aux->ticks_n_last = nt;
       ticks_sig_now = tsig;
       ticks_n_now = nt;
-      const int slots = nw + nl;  // (part of the cached plan's key)
+      const int slots = (nw + nl) | (opt_sched << 8);  // (part of the cached plan.s key)
       std::vector<int> order;
       if (aux->plan_slots == slots && aux->plan_work == work && !aux->plan_order.empty()) {
         order = aux->plan_order;  // same weights, same schedule (planning stays off the per-frame path)
@@ -1488,7 +1489,25 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
         size_t longest = 0;
         for (int x = 0; x < 8; ++x) {
           for (int t = cut[x]; t < cut[x + 1]; ++t) run[x].push_back(seq[t]);
-          std::stable_sort(run[x].begin(), run[x].end(), [&](int a, int b) { return work[a] > work[b]; });
+          if (opt_sched == 0) {
+            std::stable_sort(run[x].begin(), run[x].end(), [&](int a, int b) { return work[a] > work[b]; });
+          } else {
+            // spatially coherent dispatch: tiles that share window fringes should stream the same slices at
+            // the same time on this XCD, so that the fringe is fetched from HBM once and hit in L2 after
+            // that.  Weights only in coarse classes (longest class first), inside a class the tiles of a
+            // band column by column: 32 consecutive workgroups = a compact block of neighbours.
+            int wmax = 1;
+            for (int t : run[x]) wmax = std::max(wmax, work[t]);
+            const int classes = opt_sched == 1 ? 6 : (opt_sched == 3 ? 3 : (opt_sched == 4 ? 12 : 1));
+            const int hrows = (P.nty + 1) / 2;
+            auto key = [&](int t) -> long long {
+              const int ty = t / P.ntx, tx = t - ty * P.ntx;
+              const int cls = classes > 1 ? std::min(classes - 1, (int)((long long)work[t] * classes / ((long long)wmax + 1))) : 0;
+              const int band = ty >= hrows ? 1 : 0;
+              return (((long long)(classes - 1 - cls) * 2 + band) * 4096 + tx) * 4096 + ty;
+            };
+            std::stable_sort(run[x].begin(), run[x].end(), [&](int a, int b) { return key(a) < key(b); });
+          }
           longest = std::max(longest, run[x].size());
         }
         order.assign(longest * 8, -1);

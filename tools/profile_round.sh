@@ -1,5 +1,6 @@
 #!/bin/bash
 # Collects the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
+#   (PMC and kernel-trace passes skip the secondary legs: --no-extra)
 #   kernel-trace stats, FETCH_SIZE / WRITE_SIZE passes of the default bench command, SQ counter
 #   passes of the two ray-march workloads, and a plain bench line.  Outputs under gpurun_out/.
 set -e
@@ -8,9 +9,9 @@ R=$PWD
 O=$R/gpurun_out
 rm -rf $O/prof_final $O/pmc_final_fetch $O/pmc_final_write $O/pmc_sq_a_cfg3 $O/pmc_sq_b_cfg3 $O/pmc_sq_a_ns $O/pmc_sq_b_ns
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $O/prof_final -o run --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu > $O/prof_final.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $O/pmc_final_fetch -o f --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu > $O/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/pmc_final_write -o w --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_final -o run --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu --no-extra > $O/prof_final.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $O/pmc_final_fetch -o f --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-extra > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/pmc_final_write -o w --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-extra > $O/pmc_write.log 2>&1
 SQA="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT"
 SQB="SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_SCA"
 rocprofv3 --pmc $SQA -d $O/pmc_sq_a_cfg3 -o a --output-format csv -- python3 $R/tools/kbench.py --volume 512 --workload cfg3 --frames 3 --variants kernel=2 > $O/pmc_sq.log 2>&1
