@@ -326,6 +326,15 @@ def extra_legs(r, frame, work, steps):
     run("opaque_tf_auto", 1024, 512, "the same frame in auto mode (whichever kernel measured faster); no byte count for the gather kernel")
     if out["opaque_tf_auto"]["kernel"] == "gather":
         out["opaque_tf_auto"]["roofline"] = None
+    # cfg3 with the shadow check box on (half-angle slicing, light buffer 1024 x quality .5 = 512^2, light up-left of the eye)
+    configure(r, "cfg3", n, 1024, 512)
+    r.set_shading("r8k", (3.0, 4.0, -3.0), EYE, AT, xf, INTENS)
+    r.set_shadow(1, 1024, 0.5)
+    run("cfg3_shadows", 1024, 512, "cfg3 with gluvv.light.shadow: 512 half-angle slices, each one launch = the eye pass over 1024^2 pixels "
+        "+ the light pass over a 512^2 light buffer (per-slice recurrence: no single-march form)")
+    out["cfg3_shadows"]["kernel"] = "shadow slices"
+    out["cfg3_shadows"]["roofline"] = None   # S dependent launches: bound by the per-slice gather latency and launch cadence, not by one stream
+    r.set_shadow(0)
     # continuity with round 1: the north-star frame on round 1's input (smooth noisy shells, whose rays saturate
     # earlier: whole tiles stop streaming, which round 1's byte count ignored)
     n1 = 1024

@@ -111,9 +111,6 @@ int smk_set_shading(smk_ctx *ctx, smk_shade mode, const float light_pos[3], cons
  * plane count instead (dis = view-depth extent / steps).  With scale_alphas the 2-D TF alpha is
  * corrected as copyScale does (NV20VolRen3D.cpp:1645-1660) with rate/gamma. */
 int smk_set_sampling(smk_ctx *ctx, float sample_rate, int steps, float gamma, int scale_alphas);
-/* replaces R8kVolRen3D_cpy::createNoiseTex + gluvv.pert (R8kVolRen3D_cpy.cpp:2392-2480,
- * 1590-1595): n^3 RGBA8 noise (GL_REPEAT), weights/scales of the two live octaves. noise NULL
- * or all weights 0 turns perturbation off. */
 /* replaces the orthogonal mode of the clip-plane widget (gluvv.clip.{on,ortho,oaxis,vpos},
  * gluvv.h:163-175; NV20VolRen3D::setupClips, NV20VolRen3D.cpp:251-327): the volume is drawn only
  * on one side of an axis-aligned plane through vpos (volume space, the units of fPos/fSize).
@@ -124,8 +121,22 @@ int smk_set_clip(smk_ctx *ctx, int on, int oaxis, const float vpos[3]);
  * plane_eye = the eye-space plane OpenGL stores for that call ({0,0,-1,0} times the inverse of that
  * matrix); a sample stays when plane_eye . (x_eye, 1) >= 0.  Frames with it run on the gather kernel. */
 int smk_set_clip_plane(smk_ctx *ctx, int on, const double plane_eye[4]);
+/* replaces R8kVolRen3D_cpy::createNoiseTex + gluvv.pert (R8kVolRen3D_cpy.cpp:2392-2480,
+ * 1590-1595): n^3 RGBA8 noise (GL_REPEAT), weights/scales of the two live octaves. noise NULL
+ * or all weights 0 turns perturbation off. */
 int smk_set_perturb(smk_ctx *ctx, const unsigned char *noise_rgba, int n, const float w[4],
                     const float s[4]);
+/* replaces R8kVolRen3D's shadow mode (gluvv.light.shadow; gluvv.cpp:287-300 buffer size and qualities):
+ * half-angle slicing.  The slice axis is the half-way vector of view and light direction
+ * (R8kVolRen3D.cpp:296-326), every slice is drawn into the frame with its colour scaled by 1 - light
+ * buffer (:1651-1740, shader :2928-2934) and then composited into the light buffer (:1760-1860, shader
+ * :2991-3180) under the light's projection (LTWidgetRen::genXForm, LTWidgetRen.cpp:231-291).  Uses the
+ * light position, eye, at and xform of smk_set_shading.  buffer_px = gluvv.light.buffsz[0], quality =
+ * gluvv.light.gShadowQual or iShadowQual: the light buffer has ceil(quality * buffer_px)^2 texels.
+ * Applies to 2-D / 3-D classification with no or R8k shading on an unsharded context; other
+ * configurations make smk_render fail with the reason.  The blend order follows the light (under when
+ * the slices run away from the eye, over otherwise), smk_set_blend is not consulted. */
+int smk_set_shadow(smk_ctx *ctx, int on, int buffer_px, float quality);
 /* replaces the glBlendFunc / glBlendEquationEXT state of the slice loop (VolumeRenderer.cpp:589-590,
  * NV20VolRen3D.cpp:158-163, 930; R8kVolRen3D.cpp:1436-1449).  Default: front to back.  The two
  * "over" orders are the same operator evaluated from opposite ends (equal up to fp32 rounding);
@@ -226,6 +237,24 @@ typedef struct {
   float tau0, dtau, zmin, zmax, dis;
 } smk_raycoef;
 int smk_get_raycoef(smk_ctx *ctx, smk_raycoef *out);
+/* sample placement of a frame with shadows: slice k = 1..nslices; an eye ray's sample is fma(tau, D, Ec)
+ * with D_a = fma(px, Dx_a, fma(py, Dy_a, Dc_a)), tau = fma(k, dnum, num0) / fma(px, nDx, fma(py, nDy, nDc));
+ * a light-buffer texel's likewise from (las, lal, Lc, G*, nG*, lnum0, ldnum); X/Y/Wm map a voxel coordinate
+ * to light space, its light-buffer position is fma(x'/w, lscale, lbias) (DESIGN.md "Shadows") */
+typedef struct {
+  float pxs, pxl, pys, pyl;
+  float Ec[3], Dc[3], Dx[3], Dy[3];
+  float nDc, nDx, nDy, num0, dnum;
+  float las, lal;
+  float Lc[3], Gc[3], Gx[3], Gy[3];
+  float nGc, nGx, nGy, lnum0, ldnum;
+  float Xm[4], Ym[4], Wm[4];
+  float lscale, lbias;
+  int nslices, LB, front_to_back;
+} smk_shadowcoef;
+int smk_get_shadowcoef(smk_ctx *ctx, smk_shadowcoef *out);
+/* the light buffer as the last frame with shadows left it: [LB][LB][4] floats to HOST memory (synchronises) */
+int smk_get_light_buffer(smk_ctx *ctx, float *rgba_out, int *lb_out);
 /* options (all optional; defaults in brackets):
  *   "kernel"   [0] 0 auto: both ray-marchers produce bit-identical frames, the first frames of a new
  *              configuration time one and the other and the faster is kept; 1 gather kernel (every
@@ -237,7 +266,8 @@ int smk_get_raycoef(smk_ctx *ctx, smk_raycoef *out);
  *   diagnostics, see tools/kbench.py), "wave_w"/"blk_w" (gather tile shape), "inject_slab_status"
  *   (test hook: the next slice-ring frame reports this status word) */
 int smk_set_option(smk_ctx *ctx, const char *key, int value);
-/* last frame: which kernel ran (1/2), its HIP-event time in ms, algorithmic bytes */
+/* last frame: which kernel ran (1 gather, 2 slice-ring, 3 the per-slice shadow passes), its HIP-event time in ms,
+ * algorithmic bytes */
 int smk_last_frame_info(smk_ctx *ctx, int *kernel, float *ms, double *alg_bytes);
 /* HIP-event timing of the render kernel on its launch stream: reset, render N frames, read the
  * average (ms) over the last min(N,64) frames.  smk_timing_read synchronises the device. */

@@ -71,6 +71,18 @@ class RayCoef(C.Structure):
                 ("zmin", C.c_float), ("zmax", C.c_float), ("dis", C.c_float)]
 
 
+class ShadowCoef(C.Structure):
+    _fields_ = [("pxs", C.c_float), ("pxl", C.c_float), ("pys", C.c_float), ("pyl", C.c_float),
+                ("Ec", C.c_float * 3), ("Dc", C.c_float * 3), ("Dx", C.c_float * 3), ("Dy", C.c_float * 3),
+                ("nDc", C.c_float), ("nDx", C.c_float), ("nDy", C.c_float), ("num0", C.c_float), ("dnum", C.c_float),
+                ("las", C.c_float), ("lal", C.c_float), ("Lc", C.c_float * 3),
+                ("Gc", C.c_float * 3), ("Gx", C.c_float * 3), ("Gy", C.c_float * 3),
+                ("nGc", C.c_float), ("nGx", C.c_float), ("nGy", C.c_float), ("lnum0", C.c_float), ("ldnum", C.c_float),
+                ("Xm", C.c_float * 4), ("Ym", C.c_float * 4), ("Wm", C.c_float * 4),
+                ("lscale", C.c_float), ("lbias", C.c_float),
+                ("nslices", C.c_int), ("LB", C.c_int), ("front_to_back", C.c_int)]
+
+
 class LevWidget(C.Structure):
     _fields_ = [("type", C.c_int), ("verts", (C.c_float * 2) * 3), ("thresh", C.c_float * 2),
                 ("color", C.c_float * 3), ("alpha", C.c_float), ("be", C.c_float),
@@ -86,6 +98,11 @@ def _proto(L):
     L.orc_render_pixels.argtypes = [P(Volume), P(Classify), P(Camera), P(Shade), P(Perturb),
                                     C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     L.orc_ray_setup.argtypes = [P(Volume), P(Camera), P(RayCoef)]
+    L.orc_shadow_setup.restype = C.c_int
+    L.orc_shadow_setup.argtypes = [P(Volume), P(Camera), P(C.c_float), P(C.c_float), P(C.c_float), P(C.c_float),
+                                   C.c_int, C.c_float, P(ShadowCoef)]
+    L.orc_render_shadow.restype = C.c_int
+    L.orc_render_shadow.argtypes = [P(Volume), P(Classify), P(Camera), P(Shade), P(ShadowCoef), C.c_void_p, C.c_void_p, C.c_int]
     L.orc_last_inside_samples.restype = C.c_longlong
     L.orc_composite_over.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.orc_shade_setup.argtypes = [C.c_int, C.c_int, P(C.c_float), P(C.c_float), P(C.c_float),
@@ -196,6 +213,7 @@ class Scene:
         self.mv_override = None
         self.clip_plane = None  # free clip plane, eye space (what glClipPlane stores): keep plane . (x_eye,1) >= 0
         self.clip = None        # (axis 1..6 = X+ X- Y+ Y- Z+ Z-, vpos[3] in volume space): gluvv.clip, ortho mode
+        self.shadow = None      # (buffer_px, quality): gluvv.light.shadow with buffsz / g|iShadowQual (gluvv.cpp:287-300)
 
     def mv(self):
         if self.mv_override is not None:
@@ -278,6 +296,24 @@ class Scene:
                               _p(out), _p(dep), r0, r1, nthreads)
         assert rc == 0
         return (out, dep) if depth else out
+
+    def shadowcoef(self):
+        sc = ShadowCoef()
+        v, c = self.c_volume(), self.c_camera()
+        rc = lib().orc_shadow_setup(C.byref(v), C.byref(c), _f3(self.light_pos), _f3(self.eye), _f3(self.at),
+                                    _f3(self.xform), int(self.shadow[0]), float(self.shadow[1]), C.byref(sc))
+        assert rc == 0, "orc_shadow_setup: degenerate light"
+        return sc
+
+    def render_shadow(self, nthreads=0):
+        """half-angle-slicing frame: (rgba [H][W][4], light buffer [LB][LB][4])"""
+        sc = self.shadowcoef()
+        out = np.zeros((self.height, self.width, 4), np.float32)
+        light = np.zeros((sc.LB, sc.LB, 4), np.float32)
+        v, t, c, s = self.c_volume(), self.c_classify(), self.c_camera(), self.c_shade()
+        rc = lib().orc_render_shadow(C.byref(v), C.byref(t), C.byref(c), C.byref(s), C.byref(sc), _p(out), _p(light), nthreads)
+        assert rc == 0, rc
+        return out, light
 
     def render_pixels(self, pix, blend=0):
         pix = np.ascontiguousarray(pix, np.int32)

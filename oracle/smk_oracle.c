@@ -298,8 +298,8 @@ static inline float pow30(float x) {
 }
 
 /* returns 0 if the sample contributes nothing (alpha == 0) */
-static int shade_sample(const orc_volume *v, const orc_classify *tf, const orc_shade *sh,
-                        const orc_perturb *pt, float x, float y, float z, float src[4]) {
+static int shade_sample_s(const orc_volume *v, const orc_classify *tf, const orc_shade *sh,
+                          const orc_perturb *pt, float x, float y, float z, const float *shadow, float src[4]) {
   if (pt && pt->on) {
     /* tc' = tc + sum_m w_m*(noise(tc*s_m).rgb - 0.5), two live octaves
      * (R8kVolRen3D_cpy.cpp:1590-1595, 3462-3490); tc = (vc+0.5)/N */
@@ -370,6 +370,7 @@ static int shade_sample(const orc_volume *v, const orc_classify *tf, const orc_s
       for (int k = 0; k < 3; ++k) {
         float shaded = fmaf(c[k], kd, ks);        /* MAD col*diff + spec (:2886-2890) */
         c[k] = fmaf(g, shaded - c[k], c[k]);      /* LERP by G                        */
+        if (shadow) c[k] *= 1.0f - shadow[k];     /* MUL r0, r0, 1-r5 (:2928-2934)    */
       }
       src[0] = sat(c[0] * a); /* :2974-2977 */
       src[1] = sat(c[1] * a);
@@ -392,11 +393,39 @@ static int shade_sample(const orc_volume *v, const orc_classify *tf, const orc_s
       return 1;
     }
   }
+  if (shadow)
+    for (int k = 0; k < 3; ++k) c[k] *= 1.0f - shadow[k];
   src[0] = sat(c[0] * a);
   src[1] = sat(c[1] * a);
   src[2] = sat(c[2] * a);
   src[3] = a;
   return 1;
+}
+
+static int shade_sample(const orc_volume *v, const orc_classify *tf, const orc_shade *sh,
+                        const orc_perturb *pt, float x, float y, float z, float src[4]) {
+  return shade_sample_s(v, tf, sh, pt, x, y, z, NULL, src);
+}
+
+/* classification alone (the light-buffer pass, R8kVolRen3D.cpp:3028-3100): straight colour, alpha =
+ * sat(a_VG * a_H); returns 0 when alpha == 0 */
+static int classify_sample(const orc_volume *v, const orc_classify *tf, float x, float y, float z, float col[4]) {
+  float ch[4];
+  fetch_voxel(v, x, y, z, ch);
+  if (tf->mode == ORC_TF_2D) {
+    tex2d(tf->tf_vg, tf->sv, tf->sg, ch[0], ch[1], col);
+    if (tf->third_axis && tf->tf_h) {
+      float h[4];
+      tex2d(tf->tf_h, tf->sv, tf->sg, ch[2], ch[3], h);
+      col[3] *= h[3];
+    }
+  } else if (tf->mode == ORC_TF_3D) {
+    tex3d(tf->tf3d, tf->s3v, tf->s3g, tf->s3h, ch[0], ch[1], ch[2], col);
+  } else {
+    return 0;
+  }
+  col[3] = sat(col[3]);
+  return col[3] != 0.0f;
 }
 
 /* Free clip plane (NV20VolRen3D.cpp:346-357): glClipPlane keeps eye-space points with
@@ -525,6 +554,257 @@ int orc_render_pixels(const orc_volume *v, const orc_classify *tf, const orc_cam
 #endif
   for (int k = 0; k < npix; ++k)
     march_pixel(v, tf, sh, pt, &rc, blend, pix[2 * k], pix[2 * k + 1], out + 4 * k, NULL, cam->znear);
+  return 0;
+}
+
+/* ------------------------------------------------------------ half-angle-slicing shadows */
+
+static double dot3d(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+int orc_shadow_setup(const orc_volume *v, const orc_camera *cam, const float light_pos[3], const float eye[3],
+                     const float at[3], const float xform[16], int buffer_px, float quality, orc_shadowcoef *o) {
+  memset(o, 0, sizeof *o);
+  const double f[3] = {v->fx, v->fy, v->fz}, N[3] = {v->nx, v->ny, v->nz};
+  /* view and light direction in world space (R8kVolRen3D.cpp:296-305: axis (0,0,1) IS the world view
+   * direction of gluvv's camera; ldir = -norm(light.pos)) */
+  double vd[3] = {(double)at[0] - eye[0], (double)at[1] - eye[1], (double)at[2] - eye[2]};
+  double ld[3] = {-(double)light_pos[0], -(double)light_pos[1], -(double)light_pos[2]};
+  double vl = sqrt(dot3d(vd, vd)), d0 = sqrt(dot3d(ld, ld));
+  if (!(vl > 0) || !(d0 > 0)) return 1;
+  for (int k = 0; k < 3; ++k) { vd[k] /= vl; ld[k] /= d0; }
+  const double vdl = dot3d(vd, ld);
+  if (vdl <= 0) for (int k = 0; k < 3; ++k) vd[k] = -vd[k];   /* :307-311 */
+  double h[3];
+  for (int k = 0; k < 3; ++k) h[k] = (vd[k] - ld[k]) * .5 + ld[k];   /* (v - l)/2 + l, :316-320 */
+  o->front_to_back = vdl > 0;
+  /* model <- world for directions: inverse of rinfo.xform's linear part (mvinv . axis, :1321-1324) */
+  double xf[16], xinv[16];
+  for (int i = 0; i < 16; ++i) xf[i] = xform[i];
+  affine_inverse(xinv, xf);
+  double sn[3];
+  for (int a = 0; a < 3; ++a) sn[a] = xinv[0 + a] * h[0] + xinv[4 + a] * h[1] + xinv[8 + a] * h[2];
+  const double snl = sqrt(dot3d(sn, sn));
+  if (!(snl > 0)) return 1;
+  for (int a = 0; a < 3; ++a) sn[a] /= snl;
+  /* slice planes sn . X = c_k = tmin + k dc, k = 1..S, over the whole volume's corners */
+  double tmin = 1e300, tmax = -1e300;
+  for (int i = 0; i < 8; ++i) {
+    const double X[3] = {(i & 1) ? f[0] : 0, (i & 2) ? f[1] : 0, (i & 4) ? f[2] : 0};
+    const double t = dot3d(sn, X);
+    if (t < tmin) tmin = t;
+    if (t > tmax) tmax = t;
+  }
+  double dc;
+  int S;
+  if (cam->steps > 0) {
+    S = cam->steps;
+    dc = (tmax - tmin) / S;
+  } else {
+    const float disf = v->fx / ((float)v->nx * cam->sample_rate);  /* :1330 */
+    dc = disf;
+    S = (int)((tmax - tmin) / dc);
+  }
+  if (S < 0) S = 0;
+  o->nslices = S;
+  /* eye rays: X = e + tau (R0 px + R1 py - n R2) (see orc_ray_setup) */
+  double inv[16];
+  affine_inverse(inv, cam->mv);
+  const double n = cam->znear;
+  const double l = cam->frustum[0], r = cam->frustum[1], b = cam->frustum[2], t = cam->frustum[3];
+  o->pxs = (float)((r - l) / cam->width);
+  o->pxl = (float)l;
+  o->pys = (float)((t - b) / cam->height);
+  o->pyl = (float)b;
+  const double R0[3] = {inv[0], inv[1], inv[2]}, R1[3] = {inv[4], inv[5], inv[6]}, R2[3] = {inv[8], inv[9], inv[10]};
+  const double e[3] = {inv[12], inv[13], inv[14]};
+  for (int a = 0; a < 3; ++a) {
+    const double s = N[a] / f[a];
+    o->Ec[a] = (float)(e[a] * s - 0.5);
+    o->Dx[a] = (float)(R0[a] * s);
+    o->Dy[a] = (float)(R1[a] * s);
+    o->Dc[a] = (float)(-n * R2[a] * s);
+  }
+  o->nDx = (float)dot3d(sn, R0);
+  o->nDy = (float)dot3d(sn, R1);
+  o->nDc = (float)(-n * dot3d(sn, R2));
+  o->num0 = (float)(tmin - dot3d(sn, e));
+  o->dnum = (float)dc;
+  /* light transform (LTWidgetRen::genXForm, LTWidgetRen.cpp:231-291): gluLookAt(eye = -norm(light.pos),
+   * at 0, up y) with its z translation negated, then w = 1 + z'/d0: light-view coordinates of a world
+   * point q are x' = s.q, y' = u.q, z' = 1 - F.q (F = norm(light.pos)), w = 1 + z'/d0 */
+  const double F[3] = {-ld[0], -ld[1], -ld[2]};
+  double sv[3] = {F[1] * 0 - F[2] * 1, F[2] * 0 - F[0] * 0, F[0] * 1 - F[1] * 0};   /* F x (0,1,0) */
+  const double sl = sqrt(dot3d(sv, sv));
+  if (!(sl > 1e-12)) return 1;
+  for (int k = 0; k < 3; ++k) sv[k] /= sl;
+  const double uv[3] = {sv[1] * F[2] - sv[2] * F[1], sv[2] * F[0] - sv[0] * F[2], sv[0] * F[1] - sv[1] * F[0]};  /* s x F */
+  /* world q = xform (X - f/2) (ltxf = light.xf . xform . tb, R8kVolRen3D.cpp:1280-1290) */
+  double rowx[4], rowy[4], roww[4];   /* affine forms of the model point X */
+  for (int a = 0; a < 3; ++a) {
+    const double col[3] = {xf[4 * a + 0], xf[4 * a + 1], xf[4 * a + 2]};   /* xform's column a */
+    rowx[a] = dot3d(sv, col);
+    rowy[a] = dot3d(uv, col);
+    roww[a] = -dot3d(F, col) / d0;
+  }
+  {
+    const double tcol[3] = {xf[12], xf[13], xf[14]};
+    rowx[3] = dot3d(sv, tcol);
+    rowy[3] = dot3d(uv, tcol);
+    roww[3] = 1.0 + (1.0 - dot3d(F, tcol)) / d0;
+    for (int a = 0; a < 3; ++a) {
+      rowx[3] -= rowx[a] * f[a] * .5;
+      rowy[3] -= rowy[a] * f[a] * .5;
+      roww[3] -= roww[a] * f[a] * .5;
+    }
+  }
+  /* ... in voxel coordinates: X_a = (p_a + 1/2) f_a / N_a */
+  double cx = rowx[3], cy = rowy[3], cw = roww[3];
+  for (int a = 0; a < 3; ++a) {
+    const double sc = f[a] / N[a];
+    o->Xm[a] = (float)(rowx[a] * sc);
+    o->Ym[a] = (float)(rowy[a] * sc);
+    o->Wm[a] = (float)(roww[a] * sc);
+    cx += rowx[a] * sc * .5;
+    cy += rowy[a] * sc * .5;
+    cw += roww[a] * sc * .5;
+  }
+  o->Xm[3] = (float)cx;
+  o->Ym[3] = (float)cy;
+  o->Wm[3] = (float)cw;
+  /* light-buffer coordinates lc = (x'/w * .85 + .5) * quality, in texels of a buffer_px^2 buffer (:1673-1674) */
+  const double LBf = (double)quality * (double)buffer_px;
+  o->LB = (int)ceil(LBf);
+  if (o->LB < 1) return 1;
+  o->lscale = (float)(.85 * LBf);
+  o->lbias = (float)(.5 * LBf);
+  o->las = (float)(1.0 / (.85 * LBf));
+  o->lal = (float)(-.5 / .85);
+  /* light rays, the inverse of the above: q(w) = F (1 + d0) + w (a s + b u - d0 F); X = xform^-1 q + f/2 */
+  double apex[3], gx[3], gy[3], gc[3];
+  for (int a = 0; a < 3; ++a) {
+    apex[a] = xinv[12 + a] + f[a] * .5;
+    gx[a] = gy[a] = gc[a] = 0;
+    for (int k = 0; k < 3; ++k) {
+      apex[a] += xinv[4 * k + a] * F[k] * (1.0 + d0);
+      gx[a] += xinv[4 * k + a] * sv[k];
+      gy[a] += xinv[4 * k + a] * uv[k];
+      gc[a] += xinv[4 * k + a] * F[k] * -d0;
+    }
+  }
+  for (int a = 0; a < 3; ++a) {
+    const double s = N[a] / f[a];
+    o->Lc[a] = (float)(apex[a] * s - 0.5);
+    o->Gx[a] = (float)(gx[a] * s);
+    o->Gy[a] = (float)(gy[a] * s);
+    o->Gc[a] = (float)(gc[a] * s);
+  }
+  o->nGx = (float)dot3d(sn, gx);
+  o->nGy = (float)dot3d(sn, gy);
+  o->nGc = (float)dot3d(sn, gc);
+  o->lnum0 = (float)(tmin - dot3d(sn, apex));
+  o->ldnum = (float)dc;
+  return 0;
+}
+
+/* bilinear lookup of the light buffer, texels outside it are 0 (the rest of the pbuffer stays cleared) */
+static void light_lookup(const float *L, int LB, float lx, float ly, float out[3]) {
+  const float fx0 = floorf(lx - 0.5f), fy0 = floorf(ly - 0.5f);
+  const float fx = (lx - 0.5f) - fx0, fy = (ly - 0.5f) - fy0;
+  out[0] = out[1] = out[2] = 0.0f;
+  if (!(fx0 >= -1.0f && fx0 < (float)LB && fy0 >= -1.0f && fy0 < (float)LB)) return;   /* (also NaN) */
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  for (int k = 0; k < 3; ++k) {
+    float t[4];
+    for (int q = 0; q < 4; ++q) {
+      const int x = x0 + (q & 1), y = y0 + (q >> 1);
+      t[q] = (x >= 0 && x < LB && y >= 0 && y < LB) ? L[4 * ((size_t)y * LB + x) + k] : 0.0f;
+    }
+    out[k] = lerpf(lerpf(t[0], t[1], fx), lerpf(t[2], t[3], fx), fy);
+  }
+}
+
+int orc_render_shadow(const orc_volume *v, const orc_classify *tf, const orc_camera *cam, const orc_shade *sh,
+                      const orc_shadowcoef *sc, float *rgba, float *light_out, int nthreads) {
+  if (tf->mode == ORC_TF_1D || (sh && sh->mode == ORC_SHADE_NV20)) return 2;
+  const int W = cam->width, H = cam->height, LB = sc->LB;
+  const int N[3] = {v->nx, v->ny, v->nz};
+  float *L0 = (float *)calloc((size_t)LB * LB * 4, sizeof(float));
+  float *L1 = (float *)calloc((size_t)LB * LB * 4, sizeof(float));
+  if (!L0 || !L1) { free(L0); free(L1); return 1; }
+  memset(rgba, 0, sizeof(float) * 4 * (size_t)W * H);
+#ifdef _OPENMP
+  if (nthreads <= 0) nthreads = omp_get_max_threads();
+#endif
+  for (int k = 1; k <= sc->nslices; ++k) {
+    const float num = fmaf((float)k, sc->dnum, sc->num0), lnum = fmaf((float)k, sc->ldnum, sc->lnum0);
+    /* ---- eye pass: reads L0 (the buffer as the previous slices left it) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+#endif
+    for (int j = 0; j < H; ++j)
+      for (int i = 0; i < W; ++i) {
+        const float px = fmaf((float)i + 0.5f, sc->pxs, sc->pxl), py = fmaf((float)j + 0.5f, sc->pys, sc->pyl);
+        const float nD = fmaf(px, sc->nDx, fmaf(py, sc->nDy, sc->nDc));
+        const float tau = num / nD;
+        if (!(tau > 0.0f) || isinf(tau)) continue;
+        float p[3];
+        int in = 1;
+        for (int a = 0; a < 3; ++a) {
+          const float D = fmaf(px, sc->Dx[a], fmaf(py, sc->Dy[a], sc->Dc[a]));
+          p[a] = fmaf(tau, D, sc->Ec[a]);
+          if (!(p[a] >= -0.5f && p[a] <= (float)N[a] - 0.5f)) in = 0;
+        }
+        if (!in) continue;
+        float *C = rgba + 4 * ((size_t)j * W + i);
+        if (sc->front_to_back && C[3] == 1.0f) continue;   /* (no later sample can change the pixel) */
+        const float lw = fmaf(p[0], sc->Wm[0], fmaf(p[1], sc->Wm[1], fmaf(p[2], sc->Wm[2], sc->Wm[3])));
+        const float lx = fmaf(fmaf(p[0], sc->Xm[0], fmaf(p[1], sc->Xm[1], fmaf(p[2], sc->Xm[2], sc->Xm[3]))) / lw, sc->lscale, sc->lbias);
+        const float ly = fmaf(fmaf(p[0], sc->Ym[0], fmaf(p[1], sc->Ym[1], fmaf(p[2], sc->Ym[2], sc->Ym[3]))) / lw, sc->lscale, sc->lbias);
+        float shadow[3], src[4];
+        light_lookup(L0, LB, lx, ly, shadow);
+        if (!shade_sample_s(v, tf, sh, NULL, p[0], p[1], p[2], shadow, src)) continue;
+        if (sc->front_to_back) {
+          const float w = 1.0f - C[3];
+          for (int q = 0; q < 4; ++q) C[q] = fmaf(w, src[q], C[q]);
+        } else {
+          const float w = 1.0f - src[3];
+          for (int q = 0; q < 4; ++q) C[q] = fmaf(w, C[q], src[q]);
+        }
+      }
+    /* ---- light pass: L1 = this slice's classification composited onto L0 (LERP by alpha, saturated;
+     * alpha = sat((1-a) L.a + a), R8kVolRen3D.cpp:3150-3165) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+#endif
+    for (int y = 0; y < LB; ++y)
+      for (int x = 0; x < LB; ++x) {
+        const float *Lo = L0 + 4 * ((size_t)y * LB + x);
+        float *Ln = L1 + 4 * ((size_t)y * LB + x);
+        memcpy(Ln, Lo, 4 * sizeof(float));
+        const float a = fmaf((float)x + 0.5f, sc->las, sc->lal), b = fmaf((float)y + 0.5f, sc->las, sc->lal);
+        const float nG = fmaf(a, sc->nGx, fmaf(b, sc->nGy, sc->nGc));
+        const float w = lnum / nG;
+        if (!(w > 0.0f) || isinf(w)) continue;
+        float p[3];
+        int in = 1;
+        for (int q = 0; q < 3; ++q) {
+          const float G = fmaf(a, sc->Gx[q], fmaf(b, sc->Gy[q], sc->Gc[q]));
+          p[q] = fmaf(w, G, sc->Lc[q]);
+          if (!(p[q] >= -0.5f && p[q] <= (float)N[q] - 0.5f)) in = 0;
+        }
+        if (!in) continue;
+        float col[4];
+        if (!classify_sample(v, tf, p[0], p[1], p[2], col)) continue;
+        for (int q = 0; q < 3; ++q) Ln[q] = sat(fmaf(col[3], sat(col[q]) - Lo[q], Lo[q]));
+        Ln[3] = sat(fmaf(1.0f - col[3], Lo[3], col[3]));
+      }
+    float *t = L0;
+    L0 = L1;
+    L1 = t;
+  }
+  if (light_out) memcpy(light_out, L0, sizeof(float) * 4 * (size_t)LB * LB);
+  free(L0);
+  free(L1);
   return 0;
 }
 

@@ -110,6 +110,42 @@ int orc_render_pixels(const orc_volume *v, const orc_classify *tf, const orc_cam
                       const orc_shade *sh, const orc_perturb *pt, int blend,
                       const int *pix, int npix, float *out);
 
+/* ---- half-angle-slicing shadows (R8kVolRen3D.cpp:296-326 slice axis, :1651-1868 volShadow,
+ * :2991-3180 light-buffer shader, :2928-2934 the eye shader's 1 - shadow term; light transform
+ * LTWidgetRen.cpp:231-291).  INTENDED behaviour, stated in DESIGN.md: slices perpendicular to the
+ * half-way vector of view and light direction (view direction flipped when the light faces the
+ * viewer), marched away from the light; per slice the eye pass shades every pixel's sample by
+ * 1 - L(light-buffer position of the sample) and blends it (under when the slices run away from the
+ * eye, over otherwise), then the light pass composites the slice's classification into L.
+ * Both passes place samples with the fma chains below (shared by every implementation). */
+typedef struct {
+  float pxs, pxl, pys, pyl;     /* eye rays: px = fma(i+.5, pxs, pxl), py likewise                        */
+  float Ec[3];                  /* eye point, voxel coordinates                                           */
+  float Dc[3], Dx[3], Dy[3];    /* D_a = fma(px, Dx_a, fma(py, Dy_a, Dc_a)); sample = fma(tau, D_a, Ec_a) */
+  float nDc, nDx, nDy;          /* nD = fma(px, nDx, fma(py, nDy, nDc)); tau = fma(k, dnum, num0) / nD    */
+  float num0, dnum;
+  float las, lal;               /* light rays: a = fma(u+.5, las, lal), b = fma(v+.5, las, lal)           */
+  float Lc[3];                  /* light apex, voxel coordinates                                          */
+  float Gc[3], Gx[3], Gy[3];    /* G_a = fma(a, Gx_a, fma(b, Gy_a, Gc_a)); sample = fma(w, G_a, Lc_a)     */
+  float nGc, nGx, nGy;          /* nG likewise; w = fma(k, ldnum, lnum0) / nG                             */
+  float lnum0, ldnum;
+  float Xm[4], Ym[4], Wm[4];    /* voxel -> light space: x' = fma(p0,Xm0,fma(p1,Xm1,fma(p2,Xm2,Xm3))), y', w */
+  float lscale, lbias;          /* light-buffer pixel coordinate = fma(x'/w, lscale, lbias)               */
+  int nslices;                  /* k = 1..nslices                                                         */
+  int LB;                       /* light buffer is LB x LB texels                                         */
+  int front_to_back;            /* 1: slices run away from the eye (blend under), 0: towards it (over)    */
+} orc_shadowcoef;
+
+/* buffer_px = gluvv.light.buffsz[0] (gluvv.cpp:287), quality = g/iShadowQual (:299-300).  Returns 0 ok,
+ * 1 when the light sits on the y axis (the reference's gluLookAt(up = y) degenerates there). */
+int orc_shadow_setup(const orc_volume *v, const orc_camera *cam, const float light_pos[3], const float eye[3],
+                     const float at[3], const float xform[16], int buffer_px, float quality, orc_shadowcoef *out);
+
+/* one frame with shadows.  rgba [height][width][4] premultiplied; light_out (may be NULL) [LB][LB][4] =
+ * the light buffer after the last slice.  sh->mode NV20 and the 1-D table are refused (return 2). */
+int orc_render_shadow(const orc_volume *v, const orc_classify *tf, const orc_camera *cam, const orc_shade *sh,
+                      const orc_shadowcoef *sc, float *rgba, float *light_out, int nthreads);
+
 /* in-volume samples (alpha-independent) visited by the last orc_render call in this thread
  * group; used by bench.py to print nominal vs in-volume sample counts */
 long long orc_last_inside_samples(void);

@@ -18,7 +18,7 @@ ABI_SYMBOLS = [
     "smk_create", "smk_destroy", "smk_last_error", "smk_upload_volume",
     "smk_upload_volume_device", "smk_set_shard", "smk_set_clip", "smk_set_clip_plane", "smk_hist2d", "smk_hist2d_device", "smk_merge_fields_device", "smk_shard_order", "smk_set_tlut1d",
     "smk_set_tf2d", "smk_set_tf3d", "smk_set_camera", "smk_set_shading", "smk_set_sampling",
-    "smk_set_perturb", "smk_set_blend", "smk_render", "smk_render_device", "smk_composite_over_device",
+    "smk_set_perturb", "smk_set_blend", "smk_set_shadow", "smk_get_shadowcoef", "smk_get_light_buffer", "smk_render", "smk_render_device", "smk_composite_over_device",
     "smk_make_vgh_device", "smk_normals_vgh_device", "smk_synth_volume_device",
     "smk_get_raycoef", "smk_set_option", "smk_last_frame_info", "smk_get_stat", "smk_get_trace", "smk_get_tf2d_effective",
     "smk_timing_reset", "smk_timing_read", "smk_last_frame_id", "smk_frame_failed",
@@ -51,6 +51,18 @@ class RayCoef(C.Structure):
                 ("Bc", C.c_float * 3), ("Bx", C.c_float * 3), ("By", C.c_float * 3),
                 ("nplanes", C.c_int), ("tau0", C.c_float), ("dtau", C.c_float),
                 ("zmin", C.c_float), ("zmax", C.c_float), ("dis", C.c_float)]
+
+
+class ShadowCoef(C.Structure):
+    _fields_ = [("pxs", C.c_float), ("pxl", C.c_float), ("pys", C.c_float), ("pyl", C.c_float),
+                ("Ec", C.c_float * 3), ("Dc", C.c_float * 3), ("Dx", C.c_float * 3), ("Dy", C.c_float * 3),
+                ("nDc", C.c_float), ("nDx", C.c_float), ("nDy", C.c_float), ("num0", C.c_float), ("dnum", C.c_float),
+                ("las", C.c_float), ("lal", C.c_float), ("Lc", C.c_float * 3),
+                ("Gc", C.c_float * 3), ("Gx", C.c_float * 3), ("Gy", C.c_float * 3),
+                ("nGc", C.c_float), ("nGx", C.c_float), ("nGy", C.c_float), ("lnum0", C.c_float), ("ldnum", C.c_float),
+                ("Xm", C.c_float * 4), ("Ym", C.c_float * 4), ("Wm", C.c_float * 4),
+                ("lscale", C.c_float), ("lbias", C.c_float),
+                ("nslices", C.c_int), ("LB", C.c_int), ("front_to_back", C.c_int)]
 
 
 def library_path():
@@ -116,6 +128,9 @@ def load_library():
     L.smk_set_sampling.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_float, C.c_int]
     L.smk_set_perturb.argtypes = [C.c_void_p, C.c_void_p, C.c_int, P(C.c_float), P(C.c_float)]
     L.smk_set_blend.argtypes = [C.c_void_p, C.c_int]
+    L.smk_set_shadow.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float]
+    L.smk_get_shadowcoef.argtypes = [C.c_void_p, P(ShadowCoef)]
+    L.smk_get_light_buffer.argtypes = [C.c_void_p, C.c_void_p, P(C.c_int)]
     L.smk_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.smk_render_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.smk_composite_over_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, P(C.c_int), C.c_int,
@@ -314,6 +329,23 @@ class Renderer:
         """0 / "ftb" front to back (default), 1 / "btf" back to front, 2 / "max" GL_MAX (MIP)"""
         mode = {"ftb": 0, "btf": 1, "max": 2}.get(mode, mode)
         self._ck(self.L.smk_set_blend(self.ctx, int(mode)))
+
+    def set_shadow(self, on, buffer_px=1024, quality=0.5):
+        """gluvv.light.shadow with gluvv.light.buffsz[0] and g/iShadowQual (half-angle slicing)"""
+        self._ck(self.L.smk_set_shadow(self.ctx, int(bool(on)), int(buffer_px), float(quality)))
+
+    def shadowcoef(self):
+        sc = ShadowCoef()
+        self._ck(self.L.smk_get_shadowcoef(self.ctx, C.byref(sc)))
+        return sc
+
+    def light_buffer(self):
+        """the light buffer as the last frame with shadows left it: [LB][LB][4] float32"""
+        lb = C.c_int(0)
+        self._ck(self.L.smk_get_light_buffer(self.ctx, None, C.byref(lb)))
+        out = np.zeros((lb.value, lb.value, 4), np.float32)
+        self._ck(self.L.smk_get_light_buffer(self.ctx, out.ctypes.data_as(C.c_void_p), C.byref(lb)))
+        return out
 
     def set_option(self, key, value):
         self._ck(self.L.smk_set_option(self.ctx, key.encode(), int(value)))

@@ -77,7 +77,7 @@ extern "C" void smk_destroy(smk_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   free_volume(c);
-  void *ptrs[] = {c->d_tlut, c->d_tf_vg, c->d_tf_h, c->d_tf3d, c->d_tf_occ, c->d_noise, c->d_out, c->d_depth};
+  void *ptrs[] = {c->d_tlut, c->d_tf_vg, c->d_tf_h, c->d_tf3d, c->d_tf_occ, c->d_noise, c->d_out, c->d_depth, c->d_light[0], c->d_light[1]};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->slab.h_status) (void)hipHostFree(c->slab.h_status);
@@ -532,6 +532,179 @@ extern "C" int smk_get_raycoef(smk_ctx *c, smk_raycoef *out) {
   if (!c->have_volume || !c->have_camera) FAIL(c, "smk_get_raycoef: volume and camera must be set");
   double inv[16];
   return compute_raycoef(c, out, inv);
+}
+
+static double dot3d(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+// Half-angle slicing set-up (R8kVolRen3D.cpp:296-326; light transform LTWidgetRen.cpp:231-291; light-buffer
+// coordinates R8kVolRen3D.cpp:1664-1676), everything in double, rounded once: slice planes sn . X = tmin + k dc
+// in model space, eye rays X = e + tau (R0 px + R1 py - n R2), light rays from the apex of the light's
+// projection, and the model -> light-buffer map.  The CPU checker (orc_shadow_setup) does the same steps.
+static int compute_shadowcoef(smk_ctx *c, smk_shadowcoef *o) {
+  memset(o, 0, sizeof *o);
+  const double f[3] = {c->fsize[0], c->fsize[1], c->fsize[2]}, N[3] = {(double)c->N[0], (double)c->N[1], (double)c->N[2]};
+  double vd[3] = {(double)c->at[0] - c->eye[0], (double)c->at[1] - c->eye[1], (double)c->at[2] - c->eye[2]};
+  double ld[3] = {-(double)c->light_pos[0], -(double)c->light_pos[1], -(double)c->light_pos[2]};
+  const double vl = sqrt(dot3d(vd, vd)), d0 = sqrt(dot3d(ld, ld));
+  if (!(vl > 0) || !(d0 > 0)) FAIL(c, "smk_render: shadows need eye != at and a light away from the origin");
+  for (int k = 0; k < 3; ++k) {
+    vd[k] /= vl;
+    ld[k] /= d0;
+  }
+  const double vdl = dot3d(vd, ld);
+  if (vdl <= 0)
+    for (int k = 0; k < 3; ++k) vd[k] = -vd[k];
+  double h[3];
+  for (int k = 0; k < 3; ++k) h[k] = (vd[k] - ld[k]) * .5 + ld[k];
+  o->front_to_back = vdl > 0;
+  double xf[16], xinv[16];
+  for (int i = 0; i < 16; ++i) xf[i] = c->xform[i];
+  inverse_affine(xinv, xf);
+  double sn[3];
+  for (int a = 0; a < 3; ++a) sn[a] = xinv[0 + a] * h[0] + xinv[4 + a] * h[1] + xinv[8 + a] * h[2];
+  const double snl = sqrt(dot3d(sn, sn));
+  if (!(snl > 0)) FAIL(c, "smk_render: shadows: degenerate half-way vector");
+  for (int a = 0; a < 3; ++a) sn[a] /= snl;
+  double tmin = 1e300, tmax = -1e300;
+  for (int i = 0; i < 8; ++i) {
+    const double X[3] = {(i & 1) ? f[0] : 0, (i & 2) ? f[1] : 0, (i & 4) ? f[2] : 0};
+    const double t = dot3d(sn, X);
+    if (t < tmin) tmin = t;
+    if (t > tmax) tmax = t;
+  }
+  double dc;
+  int S;
+  if (c->steps > 0) {
+    S = c->steps;
+    dc = (tmax - tmin) / S;
+  } else {
+    const float disf = c->fsize[0] / ((float)c->N[0] * c->sample_rate);  // R8kVolRen3D.cpp:1330
+    dc = disf;
+    S = (int)((tmax - tmin) / dc);
+  }
+  if (S < 0) S = 0;
+  o->nslices = S;
+  double inv[16];
+  inverse_affine(inv, c->mv);
+  const double n = c->clip[0];
+  const double l = c->frustum[0], r = c->frustum[1], b = c->frustum[2], t = c->frustum[3];
+  o->pxs = (float)((r - l) / c->W);
+  o->pxl = (float)l;
+  o->pys = (float)((t - b) / c->H);
+  o->pyl = (float)b;
+  const double R0[3] = {inv[0], inv[1], inv[2]}, R1[3] = {inv[4], inv[5], inv[6]}, R2[3] = {inv[8], inv[9], inv[10]};
+  const double e[3] = {inv[12], inv[13], inv[14]};
+  for (int a = 0; a < 3; ++a) {
+    const double s = N[a] / f[a];
+    o->Ec[a] = (float)(e[a] * s - 0.5);
+    o->Dx[a] = (float)(R0[a] * s);
+    o->Dy[a] = (float)(R1[a] * s);
+    o->Dc[a] = (float)(-n * R2[a] * s);
+  }
+  o->nDx = (float)dot3d(sn, R0);
+  o->nDy = (float)dot3d(sn, R1);
+  o->nDc = (float)(-n * dot3d(sn, R2));
+  o->num0 = (float)(tmin - dot3d(sn, e));
+  o->dnum = (float)dc;
+  // light view: x' = s.q, y' = u.q, z' = 1 - F.q, w = 1 + z'/d0 for a world point q = xform (X - f/2)
+  const double F[3] = {-ld[0], -ld[1], -ld[2]};
+  double sv[3] = {F[1] * 0 - F[2] * 1, F[2] * 0 - F[0] * 0, F[0] * 1 - F[1] * 0};
+  const double sl = sqrt(dot3d(sv, sv));
+  if (!(sl > 1e-12)) FAIL(c, "smk_render: shadows: a light on the y axis has no light transform (gluLookAt with up = y, LTWidgetRen.cpp:262-276)");
+  for (int k = 0; k < 3; ++k) sv[k] /= sl;
+  const double uv[3] = {sv[1] * F[2] - sv[2] * F[1], sv[2] * F[0] - sv[0] * F[2], sv[0] * F[1] - sv[1] * F[0]};
+  double rowx[4], rowy[4], roww[4];
+  for (int a = 0; a < 3; ++a) {
+    const double col[3] = {xf[4 * a + 0], xf[4 * a + 1], xf[4 * a + 2]};
+    rowx[a] = dot3d(sv, col);
+    rowy[a] = dot3d(uv, col);
+    roww[a] = -dot3d(F, col) / d0;
+  }
+  {
+    const double tcol[3] = {xf[12], xf[13], xf[14]};
+    rowx[3] = dot3d(sv, tcol);
+    rowy[3] = dot3d(uv, tcol);
+    roww[3] = 1.0 + (1.0 - dot3d(F, tcol)) / d0;
+    for (int a = 0; a < 3; ++a) {
+      rowx[3] -= rowx[a] * f[a] * .5;
+      rowy[3] -= rowy[a] * f[a] * .5;
+      roww[3] -= roww[a] * f[a] * .5;
+    }
+  }
+  double cx = rowx[3], cy = rowy[3], cw = roww[3];
+  for (int a = 0; a < 3; ++a) {
+    const double sc = f[a] / N[a];
+    o->Xm[a] = (float)(rowx[a] * sc);
+    o->Ym[a] = (float)(rowy[a] * sc);
+    o->Wm[a] = (float)(roww[a] * sc);
+    cx += rowx[a] * sc * .5;
+    cy += rowy[a] * sc * .5;
+    cw += roww[a] * sc * .5;
+  }
+  o->Xm[3] = (float)cx;
+  o->Ym[3] = (float)cy;
+  o->Wm[3] = (float)cw;
+  const double LBf = (double)c->shadow_q * (double)c->shadow_px;
+  o->LB = (int)ceil(LBf);
+  if (o->LB < 1) FAIL(c, "smk_render: shadows: empty light buffer");
+  o->lscale = (float)(.85 * LBf);
+  o->lbias = (float)(.5 * LBf);
+  o->las = (float)(1.0 / (.85 * LBf));
+  o->lal = (float)(-.5 / .85);
+  double apex[3], gx[3], gy[3], gc[3];
+  for (int a = 0; a < 3; ++a) {
+    apex[a] = xinv[12 + a] + f[a] * .5;
+    gx[a] = gy[a] = gc[a] = 0;
+    for (int k = 0; k < 3; ++k) {
+      apex[a] += xinv[4 * k + a] * F[k] * (1.0 + d0);
+      gx[a] += xinv[4 * k + a] * sv[k];
+      gy[a] += xinv[4 * k + a] * uv[k];
+      gc[a] += xinv[4 * k + a] * F[k] * -d0;
+    }
+  }
+  for (int a = 0; a < 3; ++a) {
+    const double s = N[a] / f[a];
+    o->Lc[a] = (float)(apex[a] * s - 0.5);
+    o->Gx[a] = (float)(gx[a] * s);
+    o->Gy[a] = (float)(gy[a] * s);
+    o->Gc[a] = (float)(gc[a] * s);
+  }
+  o->nGx = (float)dot3d(sn, gx);
+  o->nGy = (float)dot3d(sn, gy);
+  o->nGc = (float)dot3d(sn, gc);
+  o->lnum0 = (float)(tmin - dot3d(sn, apex));
+  o->ldnum = (float)dc;
+  return 0;
+}
+
+extern "C" int smk_set_shadow(smk_ctx *c, int on, int buffer_px, float quality) {
+  if (!c) return 1;
+  if (on && (buffer_px < 1 || buffer_px > 8192 || !(quality > 0.0f) || quality > 1.0f))
+    FAIL(c, "smk_set_shadow: buffer_px in 1..8192 and quality in (0,1] (gluvvui.cpp:156-167 clamps the qualities to [.1,1])");
+  c->shadow_on = on ? 1 : 0;
+  if (on) {
+    c->shadow_px = buffer_px;
+    c->shadow_q = quality;
+  }
+  return 0;
+}
+
+extern "C" int smk_get_shadowcoef(smk_ctx *c, smk_shadowcoef *out) {
+  if (!c || !out) return 1;
+  if (!c->have_volume || !c->have_camera) FAIL(c, "smk_get_shadowcoef: volume and camera must be set");
+  return compute_shadowcoef(c, out);
+}
+
+extern "C" int smk_get_light_buffer(smk_ctx *c, float *rgba_out, int *lb_out) {
+  if (!c) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->light_lb || !c->d_light[c->light_final]) FAIL(c, "smk_get_light_buffer: no frame with shadows has been rendered");
+  if (lb_out) *lb_out = c->light_lb;
+  if (rgba_out) {
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(rgba_out, c->d_light[c->light_final], (size_t)c->light_lb * c->light_lb * 16, hipMemcpyDeviceToHost));
+  }
+  return 0;
 }
 
 static void normalize3(float v[3]) {
@@ -1001,6 +1174,40 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
   ++c->frame_id;
   c->slab.status_slot = (int)(c->frame_id % SMK_STATUS_RING);
   if (c->slab.h_status) ((volatile int *)c->slab.h_status)[c->slab.status_slot] = 0;
+  if (c->shadow_on) {
+    // ---- half-angle slicing: S launches, each the eye pass and the light pass of one slice (smk_shadow.hip)
+    const int sk = shade_kind_of(c);
+    if (c->tf_mode == 0) FAIL(c, "smk_render: shadows need a 2-D or 3-D transfer function (the 1-D table renderer has no shadow mode)");
+    if (sk == 2) FAIL(c, "smk_render: shadows are implemented for R8k shading or none (NV20 combiners: no shadow mode in NV20VolRen3D)");
+    if (c->nranks > 1) FAIL(c, "smk_render: shadows need the whole volume on one GPU (the light buffer couples every slice of every brick)");
+    if (P.pert_on || c->cplane_on || c->clip_axis || d_depth)
+      FAIL(c, "smk_render: shadows cannot be combined with perturbation, clip planes or depth output");
+    smk_shadowcoef sc;
+    if (compute_shadowcoef(c, &sc)) return 1;
+    const size_t nl = (size_t)sc.LB * sc.LB;
+    if (nl > c->light_cap) {
+      for (int k = 0; k < 2; ++k) {
+        if (c->d_light[k]) (void)hipFree(c->d_light[k]);
+        c->d_light[k] = nullptr;
+        HIPCHK(c, hipMalloc((void **)&c->d_light[k], nl * 16));
+      }
+      c->light_cap = nl;
+    }
+    HIPCHK(c, hipEventRecord(c->ev0, s));
+    HIPCHK(c, hipMemsetAsync(c->d_light[0], 0, nl * 16, s));
+    HIPCHK(c, hipMemsetAsync(d_rgba, 0, (size_t)c->W * c->H * 16, s));
+    hipError_t e = smk_launch_shadow(P, sc, c->dtype, c->tf_mode, sk, c->d_light[0], c->d_light[1], s);
+    if (e == hipErrorNotSupported) FAIL(c, "smk_render: no shadow kernel instance for this configuration");
+    HIPCHK(c, e);
+    HIPCHK(c, hipEventRecord(c->ev1, s));
+    c->light_final = sc.nslices & 1;
+    c->light_lb = sc.LB;
+    c->last_kernel = 3;
+    // per slice the frame buffer (read + write where the slice covers it) and both light buffers move again
+    c->last_alg_bytes += (double)sc.nslices * (32.0 * (double)nl);
+    c->tcount++;
+    return 0;
+  }
   // ---- auto mode: which kernel for this configuration?
   bool try_slab = c->opt_kernel != 1 && (c->tf_mode == 1 || c->tf_mode == 2);
   unsigned long long sig = 0;

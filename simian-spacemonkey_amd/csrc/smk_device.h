@@ -204,8 +204,11 @@ __device__ __forceinline__ bool smk_classify(const RenderParams &P, float ch0, f
 
 // SH: 0 none, 1 R8k, 2 NV20.  n = decoded interpolated normal, g = second data channel.
 // in: straight colour col (col.w = alpha); out: premultiplied src
+// `shadow`: the light-buffer colour at the sample (half-angle slicing), applied as the R8k eye shader does
+// -- MUL r0, r0, 1 - r5 before the colour is weighted by its opacity (R8kVolRen3D.cpp:2928-2934); null = none
 template <int SH>
-__device__ __forceinline__ float4 smk_shade_sample(const RenderParams &P, float4 col, float n0, float n1, float n2, float g) {
+__device__ __forceinline__ float4 smk_shade_sample(const RenderParams &P, float4 col, float n0, float n1, float n2, float g,
+                                                   const float *shadow = nullptr) {
   float a = col.w;
   float c[3] = {col.x, col.y, col.z};
   if (SH == 1) {
@@ -244,6 +247,10 @@ __device__ __forceinline__ float4 smk_shade_sample(const RenderParams &P, float4
     o.z = r[2];
     o.w = a;
     return o;
+  }
+  if (shadow) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] *= 1.0f - shadow[k];
   }
   return make_float4(smk_sat(c[0] * a), smk_sat(c[1] * a), smk_sat(c[2] * a), a);
 }

@@ -151,6 +151,13 @@ struct smk_ctx {
   float xform[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   float intens = .75f, amb = .05f;
 
+  // half-angle-slicing shadows (smk_set_shadow)
+  int shadow_on = 0, shadow_px = 1024;
+  float shadow_q = .5f;
+  float4 *d_light[2] = {nullptr, nullptr};  // ping-pong light buffers, light_cap texels each
+  size_t light_cap = 0;
+  int light_final = 0, light_lb = 0;        // which one the last frame finished in, and its edge
+
   // perturbation
   uint32_t *d_noise = nullptr;
   int nn = 0;
@@ -187,6 +194,9 @@ struct smk_ctx {
 // launchers (one translation unit per kernel family)
 hipError_t smk_launch_gather(const RenderParams &P, int dtype, int tf_mode, int shade_kind,
                              hipStream_t s);
+// one launch per slice (smk_shadow.hip); L0 cleared by the caller
+hipError_t smk_launch_shadow(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, int shade_kind,
+                             float4 *L0, float4 *L1, hipStream_t s);
 // returns hipErrorNotSupported (and *why) when the frame must use the gather kernel
 hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kind, int opt_T, int opt_tile, int forced,
                            const void *vox_native, const void *vox_xmajor, SlabAux *aux, const char **why,

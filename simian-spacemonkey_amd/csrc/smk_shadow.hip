@@ -1,0 +1,209 @@
+// smk_shadow.hip -- half-angle-slicing shadows: one launch per slice, the eye pass and the light pass of
+// that slice side by side in one grid.
+//
+// Replaces R8kVolRen3D's shadow mode: the slice axis half-way between view and light direction
+// (R8kVolRen3D.cpp:296-326), volShadow's two draws per slice polygon (:1651-1868: the slice into the
+// frame buffer with the light buffer bound as texture 5, then the same slice into the light buffer), the
+// light-buffer fragment shader (:2991-3180) and the eye shader's `1 - shadow` term (:2928-2934).  The
+// reference ping-pongs two pbuffers; so does this (the eye pass of slice k reads the buffer as slices
+// < k left it, the light pass writes the other one -- including the texels the slice does not cover,
+// which the reference leaves two slices stale).
+//
+// The recurrence over slices is inherent (slice k's shading needs the light buffer after slice k-1 at
+// an arbitrary position), so the frame is S small launches instead of one march; each sample is a
+// gather of 8 voxels from HBM/L2 like kernel G's.  Sample placement: the fma chains of smk_shadowcoef,
+// evaluated identically by the CPU checker.
+#include <string.h>
+
+#include "smk_device.h"
+
+struct ShadowSlice {
+  smk_shadowcoef sc;
+  const float4 *Lprev;  // [LB][LB] light buffer after the previous slices
+  float4 *Lnext;        // ... after this one
+  float num, lnum;      // numerators of this slice's ray parameters (fma(k, dnum, num0), fma(k, ldnum, lnum0))
+  int eye_bx, eye_blocks, light_bx;  // 16x16-pixel blocks: eye grid width, eye block count, light grid width
+};
+
+// the 8 corners of voxel coordinate p and the interpolated data channels (same arithmetic as kernel G)
+template <int DT, int TF, bool SHADE>
+__device__ __forceinline__ void shadow_fetch(const RenderParams &P, float p0, float p1, float p2, float &ch0, float &ch1,
+                                             float &ch2, float &ch3, float &n0, float &n1, float &n2) {
+  int x0, x1, y0, y1, z0, z1;
+  float fx, fy, fz;
+  smk_lin_clamp(p0, P.N[0], x0, x1, fx);
+  smk_lin_clamp(p1, P.N[1], y0, y1, fy);
+  smk_lin_clamp(p2, P.N[2], z0, z1, fz);
+  const int Dx = P.D[0], Dy = P.D[1];
+  size_t r00 = ((size_t)z0 * Dy + y0) * Dx, r10 = ((size_t)z0 * Dy + y1) * Dx;
+  size_t r01 = ((size_t)z1 * Dy + y0) * Dx, r11 = ((size_t)z1 * Dy + y1) * Dx;
+  const size_t c0 = (size_t)x0, c1 = (size_t)x1;
+  SmkCorner k000, k100, k010, k110, k001, k101, k011, k111;
+  if constexpr (DT == 0) {
+    smk_load_pair_u8(P, r00 + c0, r00 + c1, k000, k100);
+    smk_load_pair_u8(P, r10 + c0, r10 + c1, k010, k110);
+    smk_load_pair_u8(P, r01 + c0, r01 + c1, k001, k101);
+    smk_load_pair_u8(P, r11 + c0, r11 + c1, k011, k111);
+  } else {
+    k000 = smk_load_corner<DT>(P, r00 + c0); k100 = smk_load_corner<DT>(P, r00 + c1);
+    k010 = smk_load_corner<DT>(P, r10 + c0); k110 = smk_load_corner<DT>(P, r10 + c1);
+    k001 = smk_load_corner<DT>(P, r01 + c0); k101 = smk_load_corner<DT>(P, r01 + c1);
+    k011 = smk_load_corner<DT>(P, r11 + c0); k111 = smk_load_corner<DT>(P, r11 + c1);
+  }
+  const float sc = DT == 0 ? SMK_INV255 : 1.0f;
+  ch0 = SMK_TRI(c0);
+  ch1 = SMK_TRI(c1);
+  ch2 = ch3 = 0.f;
+  if (DT == 0) {
+    ch0 *= sc;
+    ch1 *= sc;
+  }
+  if (TF == 2 || (TF == 1 && P.third_axis)) {
+    ch2 = SMK_TRI(c2);
+    if (DT == 0) ch2 *= sc;
+    if (P.nelts == 4) {
+      ch3 = SMK_TRI(c3);
+      if (DT == 0) ch3 *= sc;
+    }
+  }
+  if (SHADE) {
+    n0 = smk_nrm(k000.nb, k100.nb, k010.nb, k110.nb, k001.nb, k101.nb, k011.nb, k111.nb, 0, fx, fy, fz);
+    n1 = smk_nrm(k000.nb, k100.nb, k010.nb, k110.nb, k001.nb, k101.nb, k011.nb, k111.nb, 1, fx, fy, fz);
+    n2 = smk_nrm(k000.nb, k100.nb, k010.nb, k110.nb, k001.nb, k101.nb, k011.nb, k111.nb, 2, fx, fy, fz);
+  }
+}
+
+// bilinear lookup of the light buffer; texels outside it are 0 (the rest of the pbuffer stays cleared)
+__device__ __forceinline__ void shadow_lookup(const float4 *L, int LB, float lx, float ly, float out[3]) {
+  const float fx0 = floorf(lx - 0.5f), fy0 = floorf(ly - 0.5f);
+  const float fx = (lx - 0.5f) - fx0, fy = (ly - 0.5f) - fy0;
+  out[0] = out[1] = out[2] = 0.0f;
+  if (!(fx0 >= -1.0f && fx0 < (float)LB && fy0 >= -1.0f && fy0 < (float)LB)) return;  // (also NaN)
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  float4 t[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int x = x0 + (q & 1), y = y0 + (q >> 1);
+    t[q] = (x >= 0 && x < LB && y >= 0 && y < LB) ? L[(size_t)y * LB + x] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  out[0] = smk_lerp(smk_lerp(t[0].x, t[1].x, fx), smk_lerp(t[2].x, t[3].x, fx), fy);
+  out[1] = smk_lerp(smk_lerp(t[0].y, t[1].y, fx), smk_lerp(t[2].y, t[3].y, fx), fy);
+  out[2] = smk_lerp(smk_lerp(t[0].z, t[1].z, fx), smk_lerp(t[2].z, t[3].z, fx), fy);
+}
+
+template <int DT, int TF, int SH>
+__global__ __launch_bounds__(256) void smk_k_shadow_slice(const RenderParams P, const ShadowSlice Q) {
+  const smk_shadowcoef &sc = Q.sc;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // a workgroup = 16x16 pixels, each wave an 8x8 sub-tile (compact footprints in the volume)
+  const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
+  if ((int)blockIdx.x < Q.eye_blocks) {
+    // ------------------------------------------------------------------ eye pass
+    const int i = ((int)blockIdx.x % Q.eye_bx) * 16 + lx, j = ((int)blockIdx.x / Q.eye_bx) * 16 + ly;
+    if (i >= P.W || j >= P.H) return;
+    const float px = __fmaf_rn((float)i + 0.5f, sc.pxs, sc.pxl), py = __fmaf_rn((float)j + 0.5f, sc.pys, sc.pyl);
+    const float nD = __fmaf_rn(px, sc.nDx, __fmaf_rn(py, sc.nDy, sc.nDc));
+    const float tau = __fdiv_rn(Q.num, nD);
+    if (!(tau > 0.0f) || isinf(tau)) return;
+    float p[3];
+    bool in = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float D = __fmaf_rn(px, sc.Dx[a], __fmaf_rn(py, sc.Dy[a], sc.Dc[a]));
+      p[a] = __fmaf_rn(tau, D, sc.Ec[a]);
+      in = in && p[a] >= -0.5f && p[a] <= (float)P.N[a] - 0.5f;
+    }
+    if (!in) return;
+    const size_t o = (size_t)j * P.W + i;
+    float4 C = P.out[o];
+    if (sc.front_to_back && C.w == 1.0f) return;  // exact: every later weight (1-A) is 0
+    float ch0, ch1, ch2, ch3, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+    shadow_fetch<DT, TF, SH != 0>(P, p[0], p[1], p[2], ch0, ch1, ch2, ch3, n0, n1, n2);
+    float4 col;
+    if (!smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col)) return;
+    const float lw = __fmaf_rn(p[0], sc.Wm[0], __fmaf_rn(p[1], sc.Wm[1], __fmaf_rn(p[2], sc.Wm[2], sc.Wm[3])));
+    const float lxx = __fmaf_rn(p[0], sc.Xm[0], __fmaf_rn(p[1], sc.Xm[1], __fmaf_rn(p[2], sc.Xm[2], sc.Xm[3])));
+    const float lyy = __fmaf_rn(p[0], sc.Ym[0], __fmaf_rn(p[1], sc.Ym[1], __fmaf_rn(p[2], sc.Ym[2], sc.Ym[3])));
+    float shadow[3];
+    shadow_lookup(Q.Lprev, sc.LB, __fmaf_rn(__fdiv_rn(lxx, lw), sc.lscale, sc.lbias),
+                  __fmaf_rn(__fdiv_rn(lyy, lw), sc.lscale, sc.lbias), shadow);
+    const float4 src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1, shadow);
+    if (sc.front_to_back) {
+      const float w = 1.0f - C.w;
+      C.x = __fmaf_rn(w, src.x, C.x);
+      C.y = __fmaf_rn(w, src.y, C.y);
+      C.z = __fmaf_rn(w, src.z, C.z);
+      C.w = __fmaf_rn(w, src.w, C.w);
+    } else {
+      const float w = 1.0f - src.w;
+      C.x = __fmaf_rn(w, C.x, src.x);
+      C.y = __fmaf_rn(w, C.y, src.y);
+      C.z = __fmaf_rn(w, C.z, src.z);
+      C.w = __fmaf_rn(w, C.w, src.w);
+    }
+    P.out[o] = C;
+  } else {
+    // ------------------------------------------------------------------ light pass
+    const int b = (int)blockIdx.x - Q.eye_blocks;
+    const int x = (b % Q.light_bx) * 16 + lx, y = (b / Q.light_bx) * 16 + ly;
+    if (x >= sc.LB || y >= sc.LB) return;
+    const size_t o = (size_t)y * sc.LB + x;
+    float4 L = Q.Lprev[o];
+    const float a = __fmaf_rn((float)x + 0.5f, sc.las, sc.lal), bb = __fmaf_rn((float)y + 0.5f, sc.las, sc.lal);
+    const float nG = __fmaf_rn(a, sc.nGx, __fmaf_rn(bb, sc.nGy, sc.nGc));
+    const float w = __fdiv_rn(Q.lnum, nG);
+    bool in = w > 0.0f && !isinf(w);
+    float p[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float G = __fmaf_rn(a, sc.Gx[q], __fmaf_rn(bb, sc.Gy[q], sc.Gc[q]));
+      p[q] = __fmaf_rn(w, G, sc.Lc[q]);
+      in = in && p[q] >= -0.5f && p[q] <= (float)P.N[q] - 0.5f;
+    }
+    if (in) {
+      float ch0, ch1, ch2, ch3, n0, n1, n2;
+      shadow_fetch<DT, TF, false>(P, p[0], p[1], p[2], ch0, ch1, ch2, ch3, n0, n1, n2);
+      float4 col;
+      if (smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col)) {
+        // LERP r0.a, r0, r5 (saturated); alpha = sat((1 - a) r5.a + a)   (R8kVolRen3D.cpp:3150-3165)
+        const float al = col.w;
+        L.x = smk_sat(__fmaf_rn(al, smk_sat(col.x) - L.x, L.x));
+        L.y = smk_sat(__fmaf_rn(al, smk_sat(col.y) - L.y, L.y));
+        L.z = smk_sat(__fmaf_rn(al, smk_sat(col.z) - L.z, L.z));
+        L.w = smk_sat(__fmaf_rn(1.0f - al, L.w, al));
+      }
+    }
+    Q.Lnext[o] = L;
+  }
+}
+
+template <int DT, int TF, int SH>
+static hipError_t run(const RenderParams &P, ShadowSlice Q, float4 *L0, float4 *L1, hipStream_t s) {
+  const smk_shadowcoef &sc = Q.sc;
+  Q.eye_bx = (P.W + 15) / 16;
+  Q.eye_blocks = Q.eye_bx * ((P.H + 15) / 16);
+  Q.light_bx = (sc.LB + 15) / 16;
+  const int blocks = Q.eye_blocks + Q.light_bx * Q.light_bx;
+  for (int k = 1; k <= sc.nslices; ++k) {
+    Q.num = fmaf((float)k, sc.dnum, sc.num0);
+    Q.lnum = fmaf((float)k, sc.ldnum, sc.lnum0);
+    Q.Lprev = (k & 1) ? L0 : L1;
+    Q.Lnext = (k & 1) ? L1 : L0;
+    hipLaunchKernelGGL((smk_k_shadow_slice<DT, TF, SH>), dim3(blocks), dim3(256), 0, s, P, Q);
+  }
+  return hipGetLastError();
+}
+
+// L0 must be cleared by the caller; after the call the light buffer is L1 for odd nslices, L0 for even ones
+hipError_t smk_launch_shadow(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, int shade_kind,
+                             float4 *L0, float4 *L1, hipStream_t s) {
+  ShadowSlice Q;
+  memset(&Q, 0, sizeof Q);
+  Q.sc = sc;
+#define CASE(D, T, S) \
+  if (dtype == D && tf_mode == T && shade_kind == S) return run<D, T, S>(P, Q, L0, L1, s);
+  CASE(0, 1, 0) CASE(0, 1, 1) CASE(0, 2, 0) CASE(0, 2, 1)
+  CASE(1, 1, 0) CASE(1, 1, 1) CASE(1, 2, 0) CASE(1, 2, 1)
+#undef CASE
+  return hipErrorNotSupported;
+}

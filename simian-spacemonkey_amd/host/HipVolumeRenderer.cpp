@@ -209,6 +209,10 @@ void HipVolumeRenderable::draw() {
   // gluvvShadeMIP: glBlendEquationEXT(GL_MAX) around renderBricks (NV20VolRen3D.cpp:158-163)
   smk_set_blend(c, gluvv.shade == gluvvShadeMIP ? SMK_BLEND_MAX : SMK_BLEND_FRONT_TO_BACK);
   smk_set_shading(c, sm, gluvv.light.pos, gluvv.env.eye, gluvv.env.at, gluvv.rinfo.xform, gluvv.light.intens, gluvv.light.amb);
+  // shadow mode (R8kVolRen3D.cpp:296-326, 1651-1868): light buffer of buffsz texels scaled by the good or the
+  // interactive quality, whichever sampling rate is in force (R8kVolRen3D::setupPBuff, :1114-1123)
+  smk_set_shadow(c, gluvv.light.shadow, gluvv.light.buffsz[0],
+                 gluvv.volren.sampleRate == gluvv.volren.goodSamp ? gluvv.light.gShadowQual : gluvv.light.iShadowQual);
   volren->renderVolume(gluvv.volren.sampleRate, mv);
   if (!volren->ok()) go = 0;
 }

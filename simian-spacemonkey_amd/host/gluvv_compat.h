@@ -265,6 +265,24 @@ struct gluvvLight {
   int buffsz[2];
   int shadow;
   int softShadow;
+  int showView;
+  int shadowTF;
+  int showShadowTF;
+  int sill;
+  float gShadowQual;
+  float iShadowQual;
+  unsigned int cubeName;
+  float *cubeKey[6];
+  int csz;
+  int load;
+  int gload;
+  int fog;
+  float fogColor[3];
+  float fogThresh;
+  float fogLimits[2];
+  int latt;
+  float lattThresh;
+  float lattLimits[2];
 };
 
 struct gluvvRInfo {
@@ -436,6 +454,8 @@ inline void gluvvCompatDefaults(gluvvGlobal &g) {
   g.light.amb = .05f;
   g.light.intens = .75f;
   g.light.buffsz[0] = g.light.buffsz[1] = 1024;
+  g.light.gShadowQual = .5f;   // gluvv.cpp:299-300
+  g.light.iShadowQual = .2f;
   for (int i = 0; i < 4; ++i) g.rinfo.xform[5 * i] = g.clip.xform[5 * i] = 1;
   g.rinfo.scale = 1;
   g.volren.sampleRate = g.volren.goodSamp = 2.5f;

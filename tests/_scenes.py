@@ -142,3 +142,7 @@ def push_scene(r, sc, grid=(1, 1, 1), upload=True):
         r.set_perturb(sc.noise, sc.pert_w, sc.pert_s)
     else:
         r.set_perturb(None, None, None)
+    if getattr(sc, "shadow", None):
+        r.set_shadow(1, *sc.shadow)
+    else:
+        r.set_shadow(0)

@@ -67,6 +67,12 @@ int main(int argc, char **argv) {
     else if (k == "plat") gluvv.plat = (gluvvPlatform)atoi(v.c_str());
     else if (k == "tfsize") sscanf(v.c_str(), "%d,%d,%d", &gluvv.tf.ptexsz[0], &gluvv.tf.ptexsz[1], &gluvv.tf.ptexsz[2]);
     else if (k == "deptex2") dep2 = slurp(v.c_str());
+    else if (k == "light") sscanf(v.c_str(), "%f,%f,%f", &gluvv.light.pos[0], &gluvv.light.pos[1], &gluvv.light.pos[2]);
+    else if (k == "shadow") {  // shadow=<buffer>,<good quality>: the GUI's shadow check box and quality spinners (gluvvui.cpp:150-167)
+      gluvv.light.shadow = 1;
+      sscanf(v.c_str(), "%d,%f", &gluvv.light.buffsz[0], &gluvv.light.gShadowQual);
+      gluvv.light.buffsz[1] = gluvv.light.buffsz[0];
+    }
     else if (k == "pert") {
       gluvv.pert.on = 1;
       sscanf(v.c_str(), "%f,%f,%f,%f", &gluvv.pert.weights[0], &gluvv.pert.weights[1], &gluvv.pert.scales[0], &gluvv.pert.scales[1]);

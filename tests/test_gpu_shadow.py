@@ -1,0 +1,118 @@
+"""GPU parity of the half-angle-slicing shadow mode (smk_set_shadow, smk_shadow.hip) against the CPU
+checker: identical set-up coefficients, frames and light buffers within the renderer's tolerance
+(max-abs <= 1e-4 on premultiplied fp32 RGBA; sample placement is bit-identical by construction)."""
+import numpy as np
+import pytest
+
+from _scenes import make_scene, push_scene
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+LIGHTS = {"eye_side": (0, 0, -5), "oblique": (3, 4, -3), "behind": (-2, 3, 4), "side": (5, 1, 0.5)}
+
+
+@pytest.fixture(scope="module")
+def R(gpu_renderer_factory):
+    r = gpu_renderer_factory()
+    yield r
+    r.close()
+
+
+def _fields(a):
+    out = {}
+    for f, _ in a._fields_:
+        v = getattr(a, f)
+        out[f] = list(v) if hasattr(v, "__len__") else v
+    return out
+
+
+def _check(R, sc, tol=TOL):
+    push_scene(R, sc)
+    assert _fields(R.shadowcoef()) == _fields(sc.shadowcoef())
+    ref, refL = sc.render_shadow()
+    got = R.render()
+    gotL = R.light_buffer()
+    assert R.last_frame_info()[0] == 3
+    assert ref[..., 3].max() > 0.05 and refL[..., 3].max() > 0.05, "vacuous scene"
+    assert gotL.shape == refL.shape
+    eL, e = np.abs(gotL - refL).max(), np.abs(got - ref).max()
+    assert eL <= tol, f"light buffer max abs err {eL}"
+    assert e <= tol, f"frame max abs err {e}"
+    return ref, got
+
+
+@pytest.mark.parametrize("light", sorted(LIGHTS))
+@pytest.mark.parametrize("f32", [False, True])
+def test_cfg3_with_shadows(R, light, f32):
+    sc = make_scene("cfg3", f32=f32, shade=1)
+    sc.light_pos = LIGHTS[light]
+    sc.shadow = (128, 0.5)
+    ref, _ = _check(R, sc)
+    plain = sc.render()
+    assert (ref[..., :3].sum() < 0.97 * plain[..., :3].sum()) or light == "behind"   # the shadow term does something
+
+
+@pytest.mark.parametrize("kind,shade,pose", [("cfg2", 0, "id"), ("cfg4", 1, "side"), ("tf3d", 0, "rot"), ("tf3d", 1, "back")])
+def test_other_classifications_and_poses(R, kind, shade, pose):
+    sc = make_scene(kind, shade=shade, pose=pose)
+    sc.light_pos = LIGHTS["oblique"]
+    sc.shadow = (96, 0.7)       # 67.2 -> 68 texels: a ragged light buffer
+    _check(R, sc)
+
+
+def test_ragged_volume_sample_rate_mode_odd_viewport(R):
+    sc = make_scene("cfg3", dims=(40, 24, 18), shade=1, size=45)
+    sc.steps, sc.sample_rate = 0, 1.5
+    sc.light_pos = LIGHTS["side"]
+    sc.shadow = (64, 1.0)
+    _check(R, sc)
+
+
+def test_shadows_off_restores_the_plain_frame(R):
+    sc = make_scene("cfg3", shade=1)
+    sc.shadow = (64, 0.5)
+    push_scene(R, sc)
+    R.render()
+    sc.shadow = None
+    push_scene(R, sc, upload=False)
+    got = R.render()
+    assert R.last_frame_info()[0] in (1, 2)
+    assert np.abs(got - sc.render()).max() <= TOL
+
+
+def test_unsupported_combinations_fail_with_the_reason(R, smk, gpu_renderer_factory):
+    sc = make_scene("cfg1")
+    sc.shadow = (64, 0.5)
+    push_scene(R, sc)
+    with pytest.raises(smk.SmkError, match="2-D or 3-D transfer function"):
+        R.render()
+    sc = make_scene("cfg3", shade=2)
+    sc.shadow = (64, 0.5)
+    push_scene(R, sc)
+    with pytest.raises(smk.SmkError, match="NV20"):
+        R.render()
+    sc = make_scene("cfg3", pert=True)
+    sc.shadow = (64, 0.5)
+    push_scene(R, sc)
+    with pytest.raises(smk.SmkError, match="perturbation"):
+        R.render()
+    sc = make_scene("cfg3")
+    sc.shadow = (64, 0.5)
+    sc.light_pos = (0, 4, 0)
+    push_scene(R, sc)
+    with pytest.raises(smk.SmkError, match="y axis"):
+        R.render()
+    with pytest.raises(smk.SmkError, match="quality"):
+        R.set_shadow(1, 64, 0.0)
+    r2 = gpu_renderer_factory()
+    try:
+        r2.set_shard(0, 2)
+        sc = make_scene("cfg3")
+        sc.shadow = (64, 0.5)
+        push_scene(r2, sc)
+        with pytest.raises(smk.SmkError, match="whole volume on one GPU"):
+            r2.render()
+    finally:
+        r2.close()
+    R.set_shadow(0)

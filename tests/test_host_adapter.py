@@ -120,6 +120,25 @@ def test_nv20_platform_selects_the_register_combiner_phong(tmp_path, O):
 
 
 @pytest.mark.gpu
+def test_shadow_check_box_through_the_renderer_slot(tmp_path, O):
+    """gluvv.light.shadow = 1 with the good sampling rate in force: the adapter hands buffsz and gShadowQual
+    to smk_set_shadow (R8kVolRen3D::setupPBuff's choice, R8kVolRen3D.cpp:1114-1123) and the frame is the
+    half-angle-slicing one"""
+    sc = make_scene("cfg3", n=24, size=40, pose="rot", shade=1)
+    sc.steps, sc.sample_rate = 0, 2.5
+    raw = sc.tf_vg
+    sc.tf_vg = O.copy_scale(raw, 2.5)
+    sc.light_pos = (3, 4, -3)
+    sc.shadow = (96, 0.5)
+    p, out = _run(tmp_path, sc, 3, 2.5, raw, extra=["light=3,4,-3", "shadow=96,0.5"])
+    assert p.returncode == 0, p.stderr
+    got = np.fromfile(out, np.float32).reshape(sc.height, sc.width, 4)
+    ref, _ = sc.render_shadow()
+    assert ref[..., 3].max() > 0.05 and np.abs(got - ref).max() <= 1e-4
+    assert np.abs(sc.render() - ref).max() > 1e-2   # (not the unshadowed frame)
+
+
+@pytest.mark.gpu
 def test_dataset_loaded_from_trex_files_renders_like_the_checker(tmp_path, O):
     """The whole load path of `gluvv data.trex`: a big-endian float data set in two pre-bricked raw
     files + its .trex description -> VolumeFiles (parse, read, byte-swap, min/max quantise) ->
