@@ -69,6 +69,14 @@ def test_ragged_volume_sample_rate_mode_odd_viewport(R):
     _check(R, sc)
 
 
+def test_larger_frame_many_slices(R):
+    """64^3 f32 volume, 160^2 viewport, 200 slices, 256^2 light buffer: the recurrence over slices does not drift"""
+    sc = make_scene("cfg4", n=64, size=160, steps=200, f32=True, shade=1, pose="diag")
+    sc.light_pos = LIGHTS["oblique"]
+    sc.shadow = (512, 0.5)
+    _check(R, sc)
+
+
 def test_shadows_off_restores_the_plain_frame(R):
     sc = make_scene("cfg3", shade=1)
     sc.shadow = (64, 0.5)
