@@ -352,7 +352,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
     ctl[3] = 0;  // error flag (bounded spins, window bound)
     for (int l = 0; l < 4; ++l) ctl[4 + l] = l < NL ? 0 : 0x7fffffff;  // absent loaders never hold anyone back
   }
-  if (tid < 32) ctl[8 + tid] = SLAB_DONE;
+  if (tid < 32) ctl[8 + tid] = (NL > 4 && tid >= 16 && tid < 12 + NL) ? 0 : SLAB_DONE;  // (ctl[24..27]: loaders 4..7)
   __syncthreads();
   {
     int lo = 0x7fffffff, hi = -0x7fffffff;
@@ -542,7 +542,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           --inflight;
           ++landed;
         }
-        if (landed != before) raw_lds_st_b32(&ctl[4 + lid], landed);
+        if (landed != before) raw_lds_st_b32(&ctl[(lid < 4 ? 4 : 20) + lid], landed);
       };
       const bool prof = DIAG && (P.lockstep & 48) != 0 && Q.diag != nullptr;  // (diagnostic: where a loader's cycles go)
       long long t_issue = 0, t_wait = 0, t_idle = 0, t_mark = 0;
@@ -648,8 +648,12 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
               src += gstep;
               dst += (unsigned)(NL * per * 1024);
               row0 += (unsigned)(NL * rpg);
-              publish_landed(issued);
+#ifndef SLAB_PUBLISH_PER_GROUP
+#define SLAB_PUBLISH_PER_GROUP 1
+#endif
+              if (SLAB_PUBLISH_PER_GROUP) publish_landed(issued);
             }
+            if (!SLAB_PUBLISH_PER_GROUP) publish_landed(issued);
 #undef SLAB_GROUP
 #undef CM
           } else if (!FIFO) {
@@ -686,7 +690,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           }
           --inflight;
           ++landed;
-          raw_lds_st_b32(&ctl[4 + lid], landed);
+          raw_lds_st_b32(&ctl[(lid < 4 ? 4 : 20) + lid], landed);
           if (prof) t_wait += (long long)__builtin_amdgcn_s_memtime() - t_mark;
         } else {
           const int flagged = raw_lds_b32(&ctl[3]);
@@ -723,6 +727,11 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       auto landed_all = [&]() -> int {
         int4 v;
         const unsigned a = (unsigned)(size_t)(lds_cptr_t)(ctl + 4);
+        if constexpr (NL > 4) {  // loaders 4..7 publish at ctl[24..27] (words that stay at SLAB_DONE when unused)
+          int4 w;
+          asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:80\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v), "=&v"(w) : "v"(a) : "memory");
+          return min(min(min(v.x, v.y), min(v.z, v.w)), min(min(w.x, w.y), min(w.z, w.w)));
+        }
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
         return min(min(v.x, v.y), min(v.z, v.w));
       };
@@ -1241,6 +1250,13 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
   else if (opt_tile == 12) { cfgs[0] = {48, 16, 4}; ncfg = 1; }
   else if (opt_tile == 13) { cfgs[0] = {16, 48, 4}; ncfg = 1; }
   else if (opt_tile == 14) { cfgs[0] = {32, 24, 2}; ncfg = 1; }
+  // (round 2: MORE loader waves -- 10+6 on 40x16 / 16x40 px, 8+8 on 32x16 / 16x32 -- on the 1024^3 frame: 5.10 / 7.76 /
+  //  6.30 / 7.21 ms against 4.33 for 12+4 on 32x24: the smaller tiles' extra fringe outweighs the issue slots)
+  else if (opt_tile == 15) { cfgs[0] = {40, 16, 6}; ncfg = 1; }
+  else if (opt_tile == 16) { cfgs[0] = {16, 40, 6}; ncfg = 1; }
+  else if (opt_tile == 17) { cfgs[0] = {32, 16, 8}; ncfg = 1; }
+  else if (opt_tile == 18) { cfgs[0] = {16, 32, 8}; ncfg = 1; }
+  else if (opt_tile == 19) { cfgs[0] = {48, 16, 4}; ncfg = 1; }
   const int upv = dtype == 0 ? 2 : 1;
   for (int ci = 0; ci < ncfg; ++ci) {
     const int tw = cfgs[ci].tw, th = cfgs[ci].th, nl = cfgs[ci].nl;
@@ -1606,7 +1622,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
   }
   // product tile shapes: 32x16 px with 8+2 waves, 32x24 px with 12+4; the others are experiment knobs (option "tile")
 #ifdef SLAB_ALL_TILES
-#define GO_NW(D, S, R) GO(D, S, R, 4, 1) GO(D, S, R, 6, 2) GO(D, S, R, 8, 1) GO(D, S, R, 8, 2) GO(D, S, R, 8, 4) GO(D, S, R, 9, 2) GO(D, S, R, 12, 2) GO(D, S, R, 12, 4)
+#define GO_NW(D, S, R) GO(D, S, R, 4, 1) GO(D, S, R, 6, 2) GO(D, S, R, 8, 1) GO(D, S, R, 8, 2) GO(D, S, R, 8, 4) GO(D, S, R, 9, 2) GO(D, S, R, 12, 2) GO(D, S, R, 12, 4) GO(D, S, R, 8, 8) GO(D, S, R, 10, 6)
 #else
 #define GO_NW(D, S, R) GO(D, S, R, 8, 2) GO(D, S, R, 12, 4)
 #endif
