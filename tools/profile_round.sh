@@ -10,6 +10,8 @@ O=$R/gpurun_out
 rm -rf $O/prof_final $O/pmc_final_fetch $O/pmc_final_write $O/pmc_sq_a_cfg3 $O/pmc_sq_b_cfg3 $O/pmc_sq_a_ns $O/pmc_sq_b_ns
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $O/prof_final -o run --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu --no-extra > $O/prof_final.log 2>&1
+rm -rf $O/prof_extra
+rocprofv3 --kernel-trace --stats -d $O/prof_extra -o run --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu > $O/prof_extra.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_final_fetch -o f --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-extra > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_final_write -o w --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu --no-extra > $O/pmc_write.log 2>&1
 SQA="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT"
