@@ -121,6 +121,9 @@ __global__ __launch_bounds__(256) void smk_k_shadow_slice(const RenderParams P, 
     shadow_fetch<DT, TF, SH != 0>(P, p[0], p[1], p[2], ch0, ch1, ch2, ch3, n0, n1, n2);
     float4 col;
     if (!smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col)) return;
+    // (the light-buffer texels depend on the position alone and could be requested before the voxels are classified,
+    //  shortening the chain of dependent gathers; measured: 12.28 vs 10.95 ms per 512-slice frame -- nine lookups in
+    //  ten are then made for transparent samples, and the slice is bound by gather throughput, not by latency)
     const float lw = __fmaf_rn(p[0], sc.Wm[0], __fmaf_rn(p[1], sc.Wm[1], __fmaf_rn(p[2], sc.Wm[2], sc.Wm[3])));
     const float lxx = __fmaf_rn(p[0], sc.Xm[0], __fmaf_rn(p[1], sc.Xm[1], __fmaf_rn(p[2], sc.Xm[2], sc.Xm[3])));
     const float lyy = __fmaf_rn(p[0], sc.Ym[0], __fmaf_rn(p[1], sc.Ym[1], __fmaf_rn(p[2], sc.Ym[2], sc.Ym[3])));

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--u8", action="store_true")
     ap.add_argument("--synth", type=int, default=1, help="1 genvol spheres (bench input), 0 round 1's smooth shells")
     ap.add_argument("--variants", nargs="*", default=["kernel=1"])
+    ap.add_argument("--shadow", default="", help="BUFFER,QUALITY: half-angle-slicing shadows with the light at (3,4,-3)")
     a = ap.parse_args()
     pkg = bench.load_package()
     r = pkg.Renderer(0)
@@ -55,6 +56,11 @@ def main():
         xform = bench.rotation(ax, deg)
         r.set_camera(bench.modelview(xform, (1.0, 1.0, 1.0)), bench.FRUSTUM, (1.0, 20.0), a.size, a.size)
         r.set_shading("r8k", bench.LIGHT, bench.EYE, bench.AT, [float(v) for v in xform.T.reshape(-1)], bench.INTENS)
+    if a.shadow:
+        buf, q = a.shadow.split(",")
+        xform = bench.rotation((1, 1, 0), 30)
+        r.set_shading("r8k", (3.0, 4.0, -3.0), bench.EYE, bench.AT, [float(v) for v in xform.T.reshape(-1)], bench.INTENS)
+        r.set_shadow(1, int(buf), float(q))
     frame = torch.zeros((a.size * a.size, 4), dtype=torch.float32, device="cuda")
     base = None
     work = torch.cuda.Stream()
