@@ -76,6 +76,11 @@ struct SlabAux {
   int order_next = 0;
   int order_cap = 0;
   std::vector<int> order_host;  // what d_order holds
+  struct Scan {  // the per-tile geometry scan of the last frame, per workgroup configuration tried (key = camera + region + tile shape)
+    std::vector<unsigned char> key;
+    double v[4] = {0, 0, 0, 0};
+    std::vector<int> work;
+  } scan[2];
   std::vector<int> plan_work, plan_order;  // the weights the last schedule was built from, and that schedule
   int plan_slots = 0;
   // per-tile workgroup durations of an earlier frame: the schedule's weights

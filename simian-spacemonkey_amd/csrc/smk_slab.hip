@@ -1271,6 +1271,24 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     // two-slice interval a window covers + texel pair + eps
     double max_eu = 0, max_ev = 0, max_drift_u = 0, max_drift_v = 0;
     std::vector<int> work((size_t)P.ntx * P.nty, 1);  // slices each tile streams (schedule weight)
+    // The scan of all tiles below is a function of camera, region and tile shape alone; a frame of an unchanged
+    // view reuses the last one (per tile ~0.3 us of double arithmetic: 0.65 ms for the 2048 tiles of a 1024^2
+    // viewport -- hidden behind a 1.9 ms kernel, but not behind the 0.3 ms one of an eighth of the volume)
+    struct ScanKey {
+      smk_raycoef rc;
+      int W, H, tw, th, as, au, av, dir, N[3], top[3];
+      float lo[3], hi[3], hin[3];
+    } key;
+    memset(&key, 0, sizeof key);
+    key.rc = P.rc;
+    key.W = P.W; key.H = P.H; key.tw = tw; key.th = th; key.as = as; key.au = Q.au; key.av = Q.av; key.dir = Q.dir;
+    for (int a = 0; a < 3; ++a) { key.N[a] = P.N[a]; key.top[a] = P.top[a]; key.lo[a] = P.lo[a]; key.hi[a] = P.hi[a]; key.hin[a] = P.hin[a]; }
+    SlabAux::Scan &scan = aux->scan[ci & 1];
+    const bool scan_hit = scan.key.size() == sizeof key && !memcmp(scan.key.data(), &key, sizeof key) && scan.work.size() == work.size();
+    if (scan_hit) {
+      max_eu = scan.v[0]; max_ev = scan.v[1]; max_drift_u = scan.v[2]; max_drift_v = scan.v[3];
+      work = scan.work;
+    } else
     for (int tyi = 0; tyi < P.nty; ++tyi)
       for (int txi = 0; txi < P.ntx; ++txi) {
         double cA[4][3], cB[4][3];
@@ -1314,6 +1332,11 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
           max_ev = std::max(max_ev, vmax - vmin);
         }
       }
+    if (!scan_hit) {  // (a scan that bailed out above returned: only complete ones are kept)
+      scan.key.assign(reinterpret_cast<const unsigned char *>(&key), reinterpret_cast<const unsigned char *>(&key) + sizeof key);
+      scan.v[0] = max_eu; scan.v[1] = max_ev; scan.v[2] = max_drift_u; scan.v[3] = max_drift_v;
+      scan.work = work;
+    }
     // a window spans s in [j-1, j+1] (2 slices of drift; 2.5 at a face; 3 where slice 1 of a
     // three-slice volume touches both); a coordinate range of extent e touches at most ceil(e) + 2
     // texels (pair included); eps for the fp32 chains

@@ -1,0 +1,30 @@
+import sys, os, time
+sys.path.insert(0, os.getcwd())
+import torch, numpy as np
+import bench
+pkg = bench.load_package()
+n = 512
+for nranks in (1, 2, 4, 8):
+    for rank in range(0, nranks, max(1, nranks // 2)):
+        r = pkg.Renderer(0)
+        if nranks > 1:
+            r.set_shard(rank, nranks)
+        vghf, nrm = bench.make_volume(r, n)
+        r.upload_volume_device(vghf.data_ptr(), (n, n, n), 3, 1, nrm.data_ptr())
+        del vghf, nrm
+        torch.cuda.empty_cache()
+        bench.configure(r, "cfg3", n, 1024, 512)
+        frame = torch.zeros((1024 * 1024, 4), dtype=torch.float32, device="cuda")
+        for _ in range(8):
+            r.render_device(frame.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        r.timing_reset()
+        t0 = time.perf_counter()
+        K = 20
+        for _ in range(K):
+            r.render_device(frame.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / K * 1e3
+        kms, kn = r.timing_read()
+        print("nranks %d rank %d: %.3f ms/frame wall, kernel %.3f ms, kernel id %d" % (nranks, rank, t, kms, r.last_frame_info()[0]), flush=True)
+        r.close()
