@@ -241,6 +241,16 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   // slice; small workgroups keep every slice the same number of instructions (cheaper bookkeeping:
   // measured 3 % on the 512^3 frame, where the loaders' issue slots are the consumers')
   constexpr bool FIFO = EARLY;
+  // Small workgroups: the loaders take WHOLE slices in turn (loader l streams slices l, l + NL, ...) instead of a share of
+  // the row groups of every slice.  A slice costs a loader ~120 scalar instructions before its first DMA (ring check,
+  // table entry, 64-bit source address, column masks); with 3 DMA instructions per loader and slice that overhead was the
+  // larger part of the loaders' time, and they were busy 90 % of the frame.  Big workgroups keep the split: their ring is
+  // too short for NL slices being filled at once.
+#ifndef SLAB_ALT
+#define SLAB_ALT 1
+#endif
+  constexpr bool ALT = SLAB_ALT && !EARLY && NL > 1;
+  constexpr int QSTEP = ALT ? NL : 1;
   extern __shared__ __align__(16) unsigned char smem[];
   // LDS carve: ring [nslots][slot_bytes] | slice table [Ds] | control words | alpha_H
   SlabEnt *wtab = reinterpret_cast<SlabEnt *>(smem + (size_t)Q.nslots * Q.slot_bytes);
@@ -350,9 +360,9 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
     ctl[0] = 0x7fffffff;
     ctl[1] = -0x7fffffff;
     ctl[3] = 0;  // error flag (bounded spins, window bound)
-    for (int l = 0; l < 4; ++l) ctl[4 + l] = l < NL ? 0 : 0x7fffffff;  // absent loaders never hold anyone back
+    for (int l = 0; l < 4; ++l) ctl[4 + l] = l < NL ? (ALT ? l : 0) : 0x7fffffff;  // absent loaders never hold anyone back
   }
-  if (tid < 32) ctl[8 + tid] = (NL > 4 && tid >= 16 && tid < 12 + NL) ? 0 : SLAB_DONE;  // (ctl[24..27]: loaders 4..7)
+  if (tid < 32) ctl[8 + tid] = (NL > 4 && tid >= 16 && tid < 12 + NL) ? (ALT ? tid - 12 : 0) : SLAB_DONE;  // (ctl[24..27]: loaders 4..7)
   __syncthreads();
   {
     int lo = 0x7fffffff, hi = -0x7fffffff;
@@ -474,7 +484,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       const char *gv = reinterpret_cast<const char *>(Q.vox);
       // row groups g = lid, lid+NL, ... of every slice are mine; a group is `per` chunks = `rpg` rows
       const int per = Q.per, rpg = Q.rpg, groups = Q.groups;
-      const int mygroups = (groups - lid + NL - 1) / NL;
+      const int mygroups = ALT ? groups : (groups - lid + NL - 1) / NL;
+      const int gl = ALT ? 0 : lid, gn = ALT ? 1 : NL;  // my first row group of a slice, and the stride to my next one
       const int mych = mygroups * per;  // DMA wave-instructions of a whole window (this loader's share)
       const unsigned strideVb = (unsigned)(Q.strideV * (long long)VB);  // bytes, < 2^32
       // unit 64*k + lane of a group sits at (row, column) = divmod(64*k + lane, wp): fixed per lane and phase k
@@ -486,10 +497,12 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
         colk[k] = g - rowk[k] * (unsigned)Q.wp;
         voff[k] = rowk[k] * strideVb + colk[k] * 16u;
       }
-      const size_t gstep = (size_t)(NL * rpg) * strideVb;  // source advance from one of my groups to the next
+      const size_t gstep = (size_t)(gn * rpg) * strideVb;  // source advance from one of my groups to the next
       const size_t strideSb = (size_t)Q.strideS * VB;
       const bool l2hot = DIAG && (P.lockstep & 8) != 0;           // (diagnostic: every slice re-reads one slice)
-      int q = 0, inflight = 0, landed = 0, idle = 0, minp = 0, slot_q = 0, fly_total = 0;
+      // (ALT: q runs over MY slices lid, lid + NL, ...; `landed` stays the published word: every slice below it that is
+      //  mine has landed, so the minimum over the loaders' words is the complete prefix as before)
+      int q = ALT ? lid : 0, inflight = 0, landed = ALT ? lid : 0, idle = 0, minp = 0, slot_q = ALT ? lid % nslots : 0, fly_total = 0;
       int fly_counts = 0;  // lane (q & 63): DMA wave-instructions of load index q (a scalar array in one VGPR)
       if (DIAG && (P.lockstep & 64)) minp = 0x3ffffff0;  // (diagnostic: free-running stream, nobody consumes)
       // progress words, read by lane 0 alone (NW <= 16 words as four b128 reads)
@@ -515,7 +528,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       // (Measured and dropped in round 2: the 64-bit source offset as two more lane arrays, and the
       //  column masks cached across slices in a VGPR bit set -- 1024^3 3.54 -> 3.74 ms: the scalar
       //  per-slice arithmetic below is cheaper than it looks, the extra VALU is not.)
-      int ent_uv = 0;
+      int ent_uv = 0, tab_base = -64;
       // EAGER PUBLICATION.  A slice used to be published when its loader, done issuing the NEXT one, waited
       // for it -- up to a slice's issue time (~0.5 us) after it had landed, on a ring that is a few slices
       // deep.  The wave's outstanding vector-memory count can be READ (s_getreg HW_REG_IB_STS: VM_CNT in
@@ -540,7 +553,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           if (out > younger) break;
           if (FIFO) fly_total -= c_old;
           --inflight;
-          ++landed;
+          landed += QSTEP;
         }
         if (landed != before) raw_lds_st_b32(&ctl[(lid < 4 ? 4 : 20) + lid], landed);
       };
@@ -561,15 +574,16 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             }
             if (q - nslots >= minp) break;
           }
-          if ((q & 63) == 0) {
-            const int ql = q + lane;
+          if ((q & ~63) != tab_base) {  // (q steps by QSTEP: entering a new block of 64 load indices, not hitting its first one)
+            tab_base = q & ~63;
+            const int ql = tab_base + lane;
             const int e = (dir > 0 ? smin + ql : smax + 1 - ql) - Q.Os;
             ent_uv = -1;
             if (ql <= npos && e >= 0 && e < Q.Ds) ent_uv = (int)raw_lds_b64(&wtab[e]).y;  // (.pack; never -1: u0 < 2^11)
           }
           const int uv = __builtin_amdgcn_readlane(ent_uv, q & 63);
           int issued = 0;  // DMA wave-instructions of this slice (this loader's share)
-          const unsigned dst0 = ring_addr + (unsigned)(slot_q * Q.slot_bytes + lid * per * 1024);
+          const unsigned dst0 = ring_addr + (unsigned)(slot_q * Q.slot_bytes + gl * per * 1024);
           if (uv != -1) {
             // (small windows: the whole shape -- the saving would not pay for the partial-group path)
             const unsigned need_u = Q.mask_need ? (((unsigned)uv >> 22) & 0x3fu) + 1u : (unsigned)Q.wu;
@@ -577,8 +591,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             const int sl = (dir > 0 ? smin + q : smax + 1 - q) - Q.Os;
             const unsigned u0 = (unsigned)uv & 0x7ffu, v0 = ((unsigned)uv >> 11) & 0x7ffu;
             const char *src = gv + (l2hot ? (size_t)0 : (size_t)sl * strideSb) + ((size_t)v0 * strideVb + (size_t)u0 * VB) +  // (64-bit: v0 * strideVb passes 4 GiB when V is the slowest axis of a 1024^3 volume)
-                              (size_t)(lid * rpg) * strideVb;
-            unsigned dst = dst0, row0 = (unsigned)(lid * rpg);
+                              (size_t)(gl * rpg) * strideVb;
+            unsigned dst = dst0, row0 = (unsigned)(gl * rpg);
             // per = wp / gcd(64, wp) is 1, 3, 5 or 7 (the host picks such a pitch)
 #define SLAB_GROUP(CHUNK)              \
   CHUNK(0)                             \
@@ -646,8 +660,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 #undef SLAB_CHUNK_MASKED
               }
               src += gstep;
-              dst += (unsigned)(NL * per * 1024);
-              row0 += (unsigned)(NL * rpg);
+              dst += (unsigned)(gn * per * 1024);
+              row0 += (unsigned)(gn * rpg);
 #ifndef SLAB_PUBLISH_PER_GROUP
 #define SLAB_PUBLISH_PER_GROUP 1
 #endif
@@ -668,9 +682,10 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             fly_counts = lane == (q & 63) ? issued : fly_counts;
             fly_total += issued;
           }
-          ++q;
+          q += QSTEP;
           ++inflight;
-          if (++slot_q == nslots) slot_q = 0;
+          slot_q += QSTEP;
+          if (slot_q >= nslots) slot_q -= nslots;  // (QSTEP <= 8 < 3 <= nslots is not guaranteed: see the host's ring check)
         }
         if (prof) {
           const long long t = __builtin_amdgcn_s_memtime();
@@ -689,7 +704,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             wait_vmcnt(mych * (inflight - 1));  // small windows: every slice is mych wave-instructions
           }
           --inflight;
-          ++landed;
+          landed += QSTEP;
           raw_lds_st_b32(&ctl[(lid < 4 ? 4 : 20) + lid], landed);
           if (prof) t_wait += (long long)__builtin_amdgcn_s_memtime() - t_mark;
         } else {
@@ -1029,8 +1044,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   }
   if (tid == 0 && Q.tile_ticks) {
     Q.tile_ticks[tile] = max((unsigned)__builtin_amdgcn_s_memrealtime() - trace_t0, 1u);
-    // (ctl[4] = loader 0's landed count, final after the barrier above; every loader streams every slice)
-    Q.tile_ticks[Q.ntiles + tile] = npos > 0 ? (unsigned)min(max(ctl[4], 0), npos + 1) : 0u;
+    // (ctl[4..7] = the loaders' landed words, final after the barrier above; their minimum = slices completely streamed)
+    Q.tile_ticks[Q.ntiles + tile] = npos > 0 ? (unsigned)min(max(min(min(ctl[4], ctl[5]), min(ctl[6], ctl[7])), 0), npos + 1) : 0u;
     Q.tile_ticks[2 * Q.ntiles + tile] = npos > 0 ? (unsigned)(npos + 1) : 0u;
   }
   if (tracing && tid == 0) {
@@ -1368,7 +1383,8 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     // re-measured with two slices in flight, 512^3 f32 1.66 -> 1.58 ms, 512^3 u8 1.72 -> 1.68,
     // 256^3 at 1024^2 1.72 -> 1.55 (the first threshold, 12 chunks, dated from five slices in flight)
     Q.mask_need = Q.chunks >= 4 ? 1 : 0;
-    if ((Q.groups + nl - 1) / nl * Q.per > 63) { if (ci + 1 < ncfg) continue; *why = "window needs more than 63 DMA chunks per loader"; return hipErrorNotSupported; }
+    const bool alt = SLAB_ALT && (nw + nl) <= 10 && nl > 1;  // (small workgroups: whole slices per loader, see the kernel)
+    if ((alt ? Q.groups : (Q.groups + nl - 1) / nl) * Q.per > 63) { if (ci + 1 < ncfg) continue; *why = "window needs more than 63 DMA chunks per loader"; return hipErrorNotSupported; }
     // light enough for this configuration?  otherwise try the next (heavier-duty) one
     if (ci + 1 < ncfg && (double)Q.chunks * 1024.0 / (nw * 64) > 16.0 * nl) continue;
 
@@ -1397,7 +1413,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     if (opt_ns >= 3 && ns > opt_ns) ns = opt_ns;  // (experiment knob: cap the ring)
     if (ns < 3) { if (ci + 1 < ncfg) continue; *why = "window does not fit LDS"; return hipErrorNotSupported; }
     Q.nslots = ns;
-    const int mych = (Q.groups + nl - 1) / nl * Q.per;  // most DMA instructions one loader issues per slice
+    const int mych = (alt ? Q.groups : (Q.groups + nl - 1) / nl) * Q.per;  // most DMA instructions one loader issues per slice
     // Slices a loader keeps in flight.  TWO: a loader publishes a slice as landed only when it stops
     // issuing and waits for the oldest one, so a deep issue window delays every consumer that polls
     // for that slice -- and two slices per loader already cover the memory latency (4 loaders x 2 x
@@ -1412,6 +1428,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     Q.wstep = std::max(0, std::min((int)ceil(fabs(Bc[as])), ns - 4));
     if (opt_T > 0) Q.wstep = std::max(0, std::min(opt_T - 1, ns - 3));  // (experiment knob: slab_T = wstep + 1)
     Q.pmask = ns >= 2 * band ? 1 : 0;
+    if (const char *e = getenv("SMK_PMASK")) Q.pmask = atoi(e);  // (experiment)
     const size_t lds = (size_t)ns * Q.slot_bytes + fixed;
     if (getenv("SMK_DEBUG"))
       fprintf(stderr, "[smk] slice-ring plan: tile %dx%d, %d+%d waves, window %d units x %d rows (pitch %d units), %d chunks/slice, %d slots of %d B, table+ctl %zu B, LDS %zu B, band %d, wstep %d, pmask %d, maxfly %d\n",
