@@ -249,8 +249,16 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 #ifndef SLAB_ALT
 #define SLAB_ALT 1
 #endif
-  constexpr bool ALT = SLAB_ALT && !EARLY && NL > 1;
-  constexpr int QSTEP = ALT ? NL : 1;
+  // Generalised: the loaders form NLG groups; group g streams slices g, g + NLG, ..., and the LPG loaders of a group
+  // share the row groups of such a slice.  Small workgroups: NLG = NL (a loader per slice).  Big ones: SLAB_BIG_NLG
+  // (1 = every loader works on every slice).
+#ifndef SLAB_BIG_NLG
+#define SLAB_BIG_NLG 2
+#endif
+  constexpr int NLG = !SLAB_ALT ? 1 : (EARLY ? ((NL % SLAB_BIG_NLG) == 0 ? SLAB_BIG_NLG : 1) : NL);
+  constexpr int LPG = NL / NLG;
+  constexpr bool ALT = NLG > 1;
+  constexpr int QSTEP = NLG;
   extern __shared__ __align__(16) unsigned char smem[];
   // LDS carve: ring [nslots][slot_bytes] | slice table [Ds] | control words | alpha_H
   SlabEnt *wtab = reinterpret_cast<SlabEnt *>(smem + (size_t)Q.nslots * Q.slot_bytes);
@@ -360,9 +368,9 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
     ctl[0] = 0x7fffffff;
     ctl[1] = -0x7fffffff;
     ctl[3] = 0;  // error flag (bounded spins, window bound)
-    for (int l = 0; l < 4; ++l) ctl[4 + l] = l < NL ? (ALT ? l : 0) : 0x7fffffff;  // absent loaders never hold anyone back
+    for (int l = 0; l < 4; ++l) ctl[4 + l] = l < NL ? l % NLG : 0x7fffffff;  // (a loader's first slice) absent loaders never hold anyone back
   }
-  if (tid < 32) ctl[8 + tid] = (NL > 4 && tid >= 16 && tid < 12 + NL) ? (ALT ? tid - 12 : 0) : SLAB_DONE;  // (ctl[24..27]: loaders 4..7)
+  if (tid < 32) ctl[8 + tid] = (NL > 4 && tid >= 16 && tid < 12 + NL) ? (tid - 12) % NLG : SLAB_DONE;  // (ctl[24..27]: loaders 4..7)
   __syncthreads();
   {
     int lo = 0x7fffffff, hi = -0x7fffffff;
@@ -484,8 +492,9 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       const char *gv = reinterpret_cast<const char *>(Q.vox);
       // row groups g = lid, lid+NL, ... of every slice are mine; a group is `per` chunks = `rpg` rows
       const int per = Q.per, rpg = Q.rpg, groups = Q.groups;
-      const int mygroups = ALT ? groups : (groups - lid + NL - 1) / NL;
-      const int gl = ALT ? 0 : lid, gn = ALT ? 1 : NL;  // my first row group of a slice, and the stride to my next one
+      const int sg = lid % NLG;          // my slices: sg, sg + NLG, ...
+      const int gl = lid / NLG, gn = LPG;  // my first row group of such a slice, and the stride to my next one
+      const int mygroups = (groups - gl + gn - 1) / gn;
       const int mych = mygroups * per;  // DMA wave-instructions of a whole window (this loader's share)
       const unsigned strideVb = (unsigned)(Q.strideV * (long long)VB);  // bytes, < 2^32
       // unit 64*k + lane of a group sits at (row, column) = divmod(64*k + lane, wp): fixed per lane and phase k
@@ -502,7 +511,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       const bool l2hot = DIAG && (P.lockstep & 8) != 0;           // (diagnostic: every slice re-reads one slice)
       // (ALT: q runs over MY slices lid, lid + NL, ...; `landed` stays the published word: every slice below it that is
       //  mine has landed, so the minimum over the loaders' words is the complete prefix as before)
-      int q = ALT ? lid : 0, inflight = 0, landed = ALT ? lid : 0, idle = 0, minp = 0, slot_q = ALT ? lid % nslots : 0, fly_total = 0;
+      int q = sg, inflight = 0, landed = sg, idle = 0, minp = 0, slot_q = sg % nslots, fly_total = 0;
       int fly_counts = 0;  // lane (q & 63): DMA wave-instructions of load index q (a scalar array in one VGPR)
       if (DIAG && (P.lockstep & 64)) minp = 0x3ffffff0;  // (diagnostic: free-running stream, nobody consumes)
       // progress words, read by lane 0 alone (NW <= 16 words as four b128 reads)
@@ -548,7 +557,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
         const int out = (int)((st & 0xfu) | (((st >> 22) & 3u) << 4));
         const int before = landed;
         while (inflight > 0) {
-          const int c_old = FIFO ? __builtin_amdgcn_readlane(fly_counts, (q - inflight) & 63) : mych;
+          const int c_old = FIFO ? __builtin_amdgcn_readlane(fly_counts, (q - inflight * QSTEP) & 63) : mych;
           const int younger = (FIFO ? fly_total : mych * inflight) - c_old + cur;
           if (out > younger) break;
           if (FIFO) fly_total -= c_old;
@@ -620,7 +629,10 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             for (int g = 0; g < mygroups; ++g) {
               if (FIFO && row0 >= need_v) break;  // nothing of this group (or the following ones) is needed: not issued, not counted
               issued += per;
-              if (row0 + (unsigned)rpg <= need_v) {
+              // (small workgroups issue every row group of the window whatever the slice needs of it -- the instruction
+              //  count is the same either way -- so a group that lies inside the window goes the branch-free way even
+              //  when its last rows are not needed; the host makes the window a whole number of groups where it can)
+              if (row0 + (unsigned)rpg <= (FIFO ? need_v : (unsigned)Q.wv)) {
                 if (per == 3) {
                   // a whole group in ONE statement: EXEC takes each chunk's column mask in turn, M0 steps
                   // through the chunks' LDS images -- three scalar instructions per chunk and no branch
@@ -698,7 +710,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
         if (inflight > 0) {
           // retire the oldest slice in flight: everything but the younger slices' DMAs is done
           if (FIFO) {
-            fly_total -= __builtin_amdgcn_readlane(fly_counts, (q - inflight) & 63);
+            fly_total -= __builtin_amdgcn_readlane(fly_counts, (q - inflight * QSTEP) & 63);
             wait_vmcnt(fly_total);
           } else {
             wait_vmcnt(mych * (inflight - 1));  // small windows: every slice is mych wave-instructions
@@ -1377,14 +1389,18 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
       Q.rpg = 64 / g;
     }
     Q.groups = (Q.wv + Q.rpg - 1) / Q.rpg;
+    // small workgroups: a window of whole row groups (its LDS image is that big anyway), see the loader's group loop
+    if ((nw + nl) <= 10 && Q.groups * Q.rpg <= Q.Dv) Q.wv = Q.groups * Q.rpg;
     Q.chunks = Q.groups * Q.per;
     Q.slot_bytes = Q.chunks * 1024;
     // per-slice extents (and with them the table-occupancy bitmap) from four chunks per slice up:
     // re-measured with two slices in flight, 512^3 f32 1.66 -> 1.58 ms, 512^3 u8 1.72 -> 1.68,
     // 256^3 at 1024^2 1.72 -> 1.55 (the first threshold, 12 chunks, dated from five slices in flight)
     Q.mask_need = Q.chunks >= 4 ? 1 : 0;
-    const bool alt = SLAB_ALT && (nw + nl) <= 10 && nl > 1;  // (small workgroups: whole slices per loader, see the kernel)
-    if ((alt ? Q.groups : (Q.groups + nl - 1) / nl) * Q.per > 63) { if (ci + 1 < ncfg) continue; *why = "window needs more than 63 DMA chunks per loader"; return hipErrorNotSupported; }
+    // loaders of one slice (see the kernel: NLG groups of LPG loaders)
+    const int nlg = !SLAB_ALT ? 1 : ((nw + nl) > 10 ? ((nl % SLAB_BIG_NLG) == 0 ? SLAB_BIG_NLG : 1) : nl);
+    const int lpg = nl / nlg;
+    if ((Q.groups + lpg - 1) / lpg * Q.per > 63) { if (ci + 1 < ncfg) continue; *why = "window needs more than 63 DMA chunks per loader"; return hipErrorNotSupported; }
     // light enough for this configuration?  otherwise try the next (heavier-duty) one
     if (ci + 1 < ncfg && (double)Q.chunks * 1024.0 / (nw * 64) > 16.0 * nl) continue;
 
@@ -1413,7 +1429,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     if (opt_ns >= 3 && ns > opt_ns) ns = opt_ns;  // (experiment knob: cap the ring)
     if (ns < 3) { if (ci + 1 < ncfg) continue; *why = "window does not fit LDS"; return hipErrorNotSupported; }
     Q.nslots = ns;
-    const int mych = (alt ? Q.groups : (Q.groups + nl - 1) / nl) * Q.per;  // most DMA instructions one loader issues per slice
+    const int mych = (Q.groups + lpg - 1) / lpg * Q.per;  // most DMA instructions one loader issues per slice
     // Slices a loader keeps in flight.  TWO: a loader publishes a slice as landed only when it stops
     // issuing and waits for the oldest one, so a deep issue window delays every consumer that polls
     // for that slice -- and two slices per loader already cover the memory latency (4 loaders x 2 x
