@@ -80,7 +80,8 @@ struct SlabAux {
     std::vector<unsigned char> key;
     double v[4] = {0, 0, 0, 0};
     std::vector<int> work;
-  } scan[2];
+  } scan[4];
+  unsigned scan_next = 0;
   std::vector<int> plan_work, plan_order;  // the weights the last schedule was built from, and that schedule
   int plan_slots = 0;
   // per-tile workgroup durations of an earlier frame: the schedule's weights

@@ -236,7 +236,10 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   constexpr int VBL = DT == 0 ? 3 : 4;   // log2
   constexpr int NTH = (NW + NL) * 64;
   // big workgroups (one per CU, 128 VGPRs each): read whole voxels, release ring slots early
-  constexpr bool EARLY = (NW + NL) > 10;
+#ifndef SLAB_BIG_WAVES
+#define SLAB_BIG_WAVES 12  // workgroups of more waves than this are "big": one per CU
+#endif
+  constexpr bool EARLY = (NW + NL) > SLAB_BIG_WAVES;
   // ... and their loaders skip the row groups a slice does not need, counting DMA instructions per
   // slice; small workgroups keep every slice the same number of instructions (cheaper bookkeeping:
   // measured 3 % on the 512^3 frame, where the loaders' issue slots are the consumers')
@@ -595,7 +598,10 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           const unsigned dst0 = ring_addr + (unsigned)(slot_q * Q.slot_bytes + gl * per * 1024);
           if (uv != -1) {
             // (small windows: the whole shape -- the saving would not pay for the partial-group path)
-            const unsigned need_u = Q.mask_need ? (((unsigned)uv >> 22) & 0x3fu) + 1u : (unsigned)Q.wu;
+#ifndef SLAB_LIGHT_FULLROWS
+#define SLAB_LIGHT_FULLROWS 0
+#endif
+            const unsigned need_u = (SLAB_LIGHT_FULLROWS && !FIFO) ? (unsigned)Q.wp : Q.mask_need ? (((unsigned)uv >> 22) & 0x3fu) + 1u : (unsigned)Q.wu;
             const unsigned need_v = Q.mask_need ? (unsigned)Q.wv - ((unsigned)uv >> 28) * (unsigned)((Q.wv + 15) / 16) : (unsigned)Q.wv;
             const int sl = (dir > 0 ? smin + q : smax + 1 - q) - Q.Os;
             const unsigned u0 = (unsigned)uv & 0x7ffu, v0 = ((unsigned)uv >> 11) & 0x7ffu;
@@ -1284,9 +1290,24 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
   else if (opt_tile == 17) { cfgs[0] = {32, 16, 8}; ncfg = 1; }
   else if (opt_tile == 18) { cfgs[0] = {16, 32, 8}; ncfg = 1; }
   else if (opt_tile == 19) { cfgs[0] = {48, 16, 4}; ncfg = 1; }
+  else if (opt_tile == 20) { cfgs[0] = {40, 16, 2}; ncfg = 1; }
+  else if (opt_tile == 21) { cfgs[0] = {16, 40, 2}; ncfg = 1; }
   const int upv = dtype == 0 ? 2 : 1;
-  for (int ci = 0; ci < ncfg; ++ci) {
-    const int tw = cfgs[ci].tw, th = cfgs[ci].th, nl = cfgs[ci].nl;
+  // Small-workgroup shape: 10 + 2 waves on 16x40 or 40x16 pixels, or 8 + 2 on 32x16 -- whichever needs the fewest DMA
+  // instructions per ray for THIS view (the window's width is rounded up to whole 128-byte units of LDS pitch, so the
+  // answer depends on the pose: cfg 3's gives 7 / 640, 8 / 640 and 6 / 512 rays, and 1.45 / 1.57 / 1.55 ms).  Two
+  // twelve-wave workgroups fill a CU's 24 wave slots at this kernel's 75-80 VGPRs; two ten-wave ones leave four idle.
+  // A probing pass sizes the candidates' windows (each scan is kept, see below), the real pass plans the winner.
+  Cfg cand[3] = {{16, 40, 2}, {40, 16, 2}, {32, 16, 2}};
+  const bool choose = opt_tile == 0 && SLAB_BIG_WAVES >= 12;
+  int best = -1;
+  double best_score = 1e300;
+  for (int pass = choose ? 0 : 1; pass < 2; ++pass) {
+  if (pass == 1 && best >= 0) cfgs[0] = cand[best];
+  const Cfg *list = pass == 0 ? cand : cfgs;
+  const int nlist = pass == 0 ? 3 : ncfg;
+  for (int ci = 0; ci < nlist; ++ci) {
+    const int tw = list[ci].tw, th = list[ci].th, nl = list[ci].nl;
     const int nw = (tw / 8) * (th / 8);
     Q.tw = tw; Q.th = th;
     P.ntx = (P.W + tw - 1) / tw;
@@ -1310,8 +1331,12 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     key.rc = P.rc;
     key.W = P.W; key.H = P.H; key.tw = tw; key.th = th; key.as = as; key.au = Q.au; key.av = Q.av; key.dir = Q.dir;
     for (int a = 0; a < 3; ++a) { key.N[a] = P.N[a]; key.top[a] = P.top[a]; key.lo[a] = P.lo[a]; key.hi[a] = P.hi[a]; key.hin[a] = P.hin[a]; }
-    SlabAux::Scan &scan = aux->scan[ci & 1];
-    const bool scan_hit = scan.key.size() == sizeof key && !memcmp(scan.key.data(), &key, sizeof key) && scan.work.size() == work.size();
+    int slot = -1;
+    for (int k = 0; k < 4; ++k)
+      if (aux->scan[k].key.size() == sizeof key && !memcmp(aux->scan[k].key.data(), &key, sizeof key) && aux->scan[k].work.size() == work.size()) slot = k;
+    const bool scan_hit = slot >= 0;
+    if (!scan_hit) slot = aux->scan_next++ & 3;
+    SlabAux::Scan &scan = aux->scan[slot];
     if (scan_hit) {
       max_eu = scan.v[0]; max_ev = scan.v[1]; max_drift_u = scan.v[2]; max_drift_v = scan.v[3];
       work = scan.work;
@@ -1379,7 +1404,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     // per = wp / gcd(64, wp) chunks = rpg = 64 / gcd(64, wp) rows ("group")
     Q.wu = Wu / upv;
     Q.wv = Wv;
-    if (Q.wu > 64) { if (ci + 1 < ncfg) continue; *why = "window wider than one DMA chunk"; return hipErrorNotSupported; }
+    if (Q.wu > 64) { if (ci + 1 < nlist || pass == 0) continue; *why = "window wider than one DMA chunk"; return hipErrorNotSupported; }
     if (Q.Du > 2047 || Q.Dv > 2047) { *why = "stored box wider than 2047 voxels across the view"; return hipErrorNotSupported; }
     Q.wp = (Q.wu + 7) & ~7;
     {
@@ -1390,19 +1415,24 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     }
     Q.groups = (Q.wv + Q.rpg - 1) / Q.rpg;
     // small workgroups: a window of whole row groups (its LDS image is that big anyway), see the loader's group loop
-    if ((nw + nl) <= 10 && Q.groups * Q.rpg <= Q.Dv) Q.wv = Q.groups * Q.rpg;
+    if ((nw + nl) <= SLAB_BIG_WAVES && Q.groups * Q.rpg <= Q.Dv) Q.wv = Q.groups * Q.rpg;
     Q.chunks = Q.groups * Q.per;
+    if (pass == 0) {  // probing: DMA instructions per ray
+      const double score = (double)Q.chunks / (nw * 64);
+      if (score < best_score) { best_score = score; best = ci; }
+      continue;
+    }
     Q.slot_bytes = Q.chunks * 1024;
     // per-slice extents (and with them the table-occupancy bitmap) from four chunks per slice up:
     // re-measured with two slices in flight, 512^3 f32 1.66 -> 1.58 ms, 512^3 u8 1.72 -> 1.68,
     // 256^3 at 1024^2 1.72 -> 1.55 (the first threshold, 12 chunks, dated from five slices in flight)
     Q.mask_need = Q.chunks >= 4 ? 1 : 0;
     // loaders of one slice (see the kernel: NLG groups of LPG loaders)
-    const int nlg = !SLAB_ALT ? 1 : ((nw + nl) > 10 ? ((nl % SLAB_BIG_NLG) == 0 ? SLAB_BIG_NLG : 1) : nl);
+    const int nlg = !SLAB_ALT ? 1 : ((nw + nl) > SLAB_BIG_WAVES ? ((nl % SLAB_BIG_NLG) == 0 ? SLAB_BIG_NLG : 1) : nl);
     const int lpg = nl / nlg;
-    if ((Q.groups + lpg - 1) / lpg * Q.per > 63) { if (ci + 1 < ncfg) continue; *why = "window needs more than 63 DMA chunks per loader"; return hipErrorNotSupported; }
+    if ((Q.groups + lpg - 1) / lpg * Q.per > 63) { if (ci + 1 < nlist) continue; *why = "window needs more than 63 DMA chunks per loader"; return hipErrorNotSupported; }
     // light enough for this configuration?  otherwise try the next (heavier-duty) one
-    if (ci + 1 < ncfg && (double)Q.chunks * 1024.0 / (nw * 64) > 16.0 * nl) continue;
+    if (ci + 1 < nlist && (double)Q.chunks * 1024.0 / (nw * 64) > 16.0 * nl) continue;
 
     Q.use_ah = (tf_mode == 1 && P.third_axis && P.nelts <= 3 && P.sv >= 2 && P.sv <= 2048) ? 1 : 0;
     if (tf_mode == 1 && (P.sv < 2 || P.sg < 2)) { *why = "transfer function smaller than 2x2"; return hipErrorNotSupported; }
@@ -1413,7 +1443,8 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     Q.use_occ = (Q.fast_tf && Q.mask_need && P.tf_occ && occ_bytes > 0 && occ_bytes <= 8192) ? 1 : 0;
     const size_t fixed = (size_t)Q.Ds * sizeof(SlabEnt) + (8 + 32) * 4 + 64 + (Q.use_ah ? (size_t)P.sv * 4 : 0) + (Q.use_occ ? occ_bytes : 0);
     // ring: as many slots as fit two workgroups per CU (small tiles) or one (big tiles)
-    size_t budget = (nw + nl) * 64 > 640 ? 158 * 1024 : 78 * 1024;
+    size_t budget = (nw + nl) > SLAB_BIG_WAVES ? 158 * 1024 : 78 * 1024;
+    if (const char *e = getenv("SMK_LDS_BUDGET_KB")) budget = (size_t)atoi(e) * 1024;  // (experiment)
     if (budget <= fixed) { *why = "slice table does not fit LDS"; return hipErrorNotSupported; }
     int ns = (int)((budget - fixed) / (size_t)Q.slot_bytes);
     if (ns > 24) ns = 24;
@@ -1422,12 +1453,12 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     if (ns < band + 2 && 158 * 1024 > fixed) {
       // the ring of a small workgroup does not fit half a CU: one workgroup per CU it is -- then
       // rather the big tile with 16 waves than this one with 10
-      if (ci + 1 < ncfg && budget < 158 * 1024) continue;
+      if (ci + 1 < nlist && budget < 158 * 1024) continue;
       ns = (int)((158 * 1024 - fixed) / (size_t)Q.slot_bytes);
       if (ns > band + 4) ns = band + 4;
     }
     if (opt_ns >= 3 && ns > opt_ns) ns = opt_ns;  // (experiment knob: cap the ring)
-    if (ns < 3) { if (ci + 1 < ncfg) continue; *why = "window does not fit LDS"; return hipErrorNotSupported; }
+    if (ns < 3) { if (ci + 1 < nlist) continue; *why = "window does not fit LDS"; return hipErrorNotSupported; }
     Q.nslots = ns;
     const int mych = (Q.groups + lpg - 1) / lpg * Q.per;  // most DMA instructions one loader issues per slice
     // Slices a loader keeps in flight.  TWO: a loader publishes a slice as landed only when it stops
@@ -1666,7 +1697,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
 #define GO(D, S, R, N, L)                                                                              \
   if (dtype == D && shade_kind == S && Q.perm == R && nw == N && nl == L) {                          \
     if (tf_mode == 2) {                                                                              \
-      if constexpr ((N == 8 && L == 2) || (N == 12 && L == 4))                                       \
+      if constexpr ((N == 8 && L == 2) || (N == 10 && L == 2) || (N == 12 && L == 4))                \
         return after_launch(launch_slab<D, S, R, N, L, false, 2>(P, Q, lds, nblocks, s));            \
       *why = "no dense-3-D-table instance for this tile size";                                       \
       return hipErrorNotSupported;                                                                   \
@@ -1678,9 +1709,9 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
   }
   // product tile shapes: 32x16 px with 8+2 waves, 32x24 px with 12+4; the others are experiment knobs (option "tile")
 #ifdef SLAB_ALL_TILES
-#define GO_NW(D, S, R) GO(D, S, R, 4, 1) GO(D, S, R, 6, 2) GO(D, S, R, 8, 1) GO(D, S, R, 8, 2) GO(D, S, R, 8, 4) GO(D, S, R, 9, 2) GO(D, S, R, 12, 2) GO(D, S, R, 12, 4) GO(D, S, R, 8, 8) GO(D, S, R, 10, 6)
+#define GO_NW(D, S, R) GO(D, S, R, 4, 1) GO(D, S, R, 6, 2) GO(D, S, R, 8, 1) GO(D, S, R, 8, 2) GO(D, S, R, 8, 4) GO(D, S, R, 9, 2) GO(D, S, R, 12, 2) GO(D, S, R, 12, 4) GO(D, S, R, 8, 8) GO(D, S, R, 10, 6) GO(D, S, R, 10, 2)
 #else
-#define GO_NW(D, S, R) GO(D, S, R, 8, 2) GO(D, S, R, 12, 4)
+#define GO_NW(D, S, R) GO(D, S, R, 8, 2) GO(D, S, R, 10, 2) GO(D, S, R, 12, 4)
 #endif
 #define GO_R(D, S) GO_NW(D, S, 0) GO_NW(D, S, 1) GO_NW(D, S, 2)
 #ifdef SLAB_FEW_INSTANCES
@@ -1694,6 +1725,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     *why = "no kernel instance for this tile size";
     return hipErrorNotSupported;
   }
+  }  // pass
   (void)forced;
   *why = "no configuration fits";
   return hipErrorNotSupported;
