@@ -228,7 +228,11 @@ __device__ __forceinline__ float slab_tex_chan(const SlabTexel4 &x, int k) {
 // TF: 1 = 2-D (V,G) table x optional third-axis alpha (NV20VolRen3D.cpp:544-596), 2 = dense 3-D (v,g,h)
 // table (TFWidgetRen.cpp:779-845; BASELINE configs 4/5)
 template <int DT, int SH, int PERM, int NW, int NL, bool DIAG, int TF = 1>
-__global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) == 5 || (NW + NL) == 10) ? 5 : ((NW + NL) == 11 ? 3 : 4)) void smk_k_slab(const RenderParams P, const SlabParams Q) {
+#ifndef SLAB_BIG_WAVES
+#define SLAB_BIG_WAVES 12  // workgroups of more waves than this are "big": one per CU
+#endif
+// (second argument: waves per SIMD the register allocation must allow -- two small workgroups per CU)
+__global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) == 5 || (NW + NL) == 10) ? 5 : ((NW + NL) == 11 ? 3 : ((NW + NL) == 12 && 12 <= SLAB_BIG_WAVES) ? 6 : ((NW + NL) == 14 && 14 <= SLAB_BIG_WAVES) ? 7 : 4)) void smk_k_slab(const RenderParams P, const SlabParams Q) {
   constexpr int UPV = DT == 0 ? 2 : 1;   // voxels per 16-byte DMA unit
   constexpr int VB = DT == 0 ? 8 : 16;   // bytes per voxel
   // (global_load_lds_dwordx3 does NOT compact: it writes 12 bytes per lane at a 16-byte lane stride
@@ -236,9 +240,6 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   constexpr int VBL = DT == 0 ? 3 : 4;   // log2
   constexpr int NTH = (NW + NL) * 64;
   // big workgroups (one per CU, 128 VGPRs each): read whole voxels, release ring slots early
-#ifndef SLAB_BIG_WAVES
-#define SLAB_BIG_WAVES 12  // workgroups of more waves than this are "big": one per CU
-#endif
   constexpr bool EARLY = (NW + NL) > SLAB_BIG_WAVES;
   // ... and their loaders skip the row groups a slice does not need, counting DMA instructions per
   // slice; small workgroups keep every slice the same number of instructions (cheaper bookkeeping:
@@ -1290,6 +1291,8 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
   else if (opt_tile == 17) { cfgs[0] = {32, 16, 8}; ncfg = 1; }
   else if (opt_tile == 18) { cfgs[0] = {16, 32, 8}; ncfg = 1; }
   else if (opt_tile == 19) { cfgs[0] = {48, 16, 4}; ncfg = 1; }
+  else if (opt_tile == 22) { cfgs[0] = {16, 48, 2}; ncfg = 1; }
+  else if (opt_tile == 23) { cfgs[0] = {48, 16, 2}; ncfg = 1; }
   else if (opt_tile == 20) { cfgs[0] = {40, 16, 2}; ncfg = 1; }
   else if (opt_tile == 21) { cfgs[0] = {16, 40, 2}; ncfg = 1; }
   const int upv = dtype == 0 ? 2 : 1;
