@@ -244,7 +244,10 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   // ... and their loaders skip the row groups a slice does not need, counting DMA instructions per
   // slice; small workgroups keep every slice the same number of instructions (cheaper bookkeeping:
   // measured 3 % on the 512^3 frame, where the loaders' issue slots are the consumers')
-  constexpr bool FIFO = EARLY;
+#ifndef SLAB_SMALL_FIFO
+#define SLAB_SMALL_FIFO 0
+#endif
+  constexpr bool FIFO = EARLY || SLAB_SMALL_FIFO;
   // Small workgroups: the loaders take WHOLE slices in turn (loader l streams slices l, l + NL, ...) instead of a share of
   // the row groups of every slice.  A slice costs a loader ~120 scalar instructions before its first DMA (ring check,
   // table entry, 64-bit source address, column masks); with 3 DMA instructions per loader and slice that overhead was the
@@ -639,7 +642,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
               // (small workgroups issue every row group of the window whatever the slice needs of it -- the instruction
               //  count is the same either way -- so a group that lies inside the window goes the branch-free way even
               //  when its last rows are not needed; the host makes the window a whole number of groups where it can)
-              if (row0 + (unsigned)rpg <= (FIFO ? need_v : (unsigned)Q.wv)) {
+              if (row0 + (unsigned)rpg <= (EARLY ? need_v : (unsigned)Q.wv)) {
                 if (per == 3) {
                   // a whole group in ONE statement: EXEC takes each chunk's column mask in turn, M0 steps
                   // through the chunks' LDS images -- three scalar instructions per chunk and no branch
