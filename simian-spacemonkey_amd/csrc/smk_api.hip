@@ -77,7 +77,13 @@ extern "C" void smk_destroy(smk_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   free_volume(c);
-  void *ptrs[] = {c->d_tlut, c->d_tf_vg, c->d_tf_h, c->d_tf3d, c->d_tf_occ, c->d_noise, c->d_out, c->d_depth, c->d_light[0], c->d_light[1]};
+  for (smk_ctx::TfVersion &T : c->tfv) {
+    if (T.d) (void)hipFree(T.d);
+    if (T.h) (void)hipHostFree(T.h);
+    if (T.copied) (void)hipEventDestroy(T.copied);
+    if (T.used) (void)hipEventDestroy(T.used);
+  }
+  void *ptrs[] = {c->d_tlut, c->d_tf_h, c->d_tf3d, c->d_noise, c->d_out, c->d_depth, c->d_light[0], c->d_light[1]};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->slab.h_status) (void)hipHostFree(c->slab.h_status);
@@ -759,7 +765,13 @@ static void shading_vectors(const smk_ctx *c, RenderParams &P) {
 }
 
 // NV20VolRen3D::copyScale (:1645-1660) with the rate the renderer would pass (:94-98, :117)
-static int refresh_tf2d(smk_ctx *c, const smk_raycoef &rc) {
+// The effective (V,G) table of a frame: opacity correction as copyScale does it, plus the occupancy bitmap.  In steps
+// mode the correction rate follows the view-depth extent, i.e. it changes with every camera move: the table is then
+// rebuilt per frame, so the rebuild must not stall the pipeline -- a 256-entry map of the alpha byte (the correction is a
+// function of that byte alone; same arithmetic), and four versions on the device filled by stream-ordered copies from
+// pinned staging (a version is rewritten only after the last frame that read it: an event wait ON THE STREAM, not on the
+// host).  Before: hipFree + hipMalloc + hipMemcpy per refresh = a device synchronisation and 1.6 ms of pow() per frame.
+static int refresh_tf2d(smk_ctx *c, const smk_raycoef &rc, hipStream_t s) {
   if (c->tf_mode != 1) return 0;
   float sr;
   if (c->scale_alphas) {
@@ -769,32 +781,59 @@ static int refresh_tf2d(smk_ctx *c, const smk_raycoef &rc) {
     sr = 1 / c->gamma;
   }
   if (!c->tf_dirty && sr == c->tf_rate_applied && c->d_tf_vg) return 0;
-  size_t n = (size_t)c->sv * c->sg;
+  const size_t n = (size_t)c->sv * c->sg;
+  const int sv = c->sv, sg = c->sg, roww = (sv + 31) / 32;
+  const size_t occ_words = (size_t)roww * sg, bytes = n * 4 + occ_words * 4;
+  const int v = (c->tf_cur + 1) & 3;
+  smk_ctx::TfVersion &T = c->tfv[v];
+  if (T.cap < bytes) {  // (a new table size: rare)
+    if (T.copied) (void)hipEventSynchronize(T.copied);
+    if (T.used_valid) (void)hipEventSynchronize(T.used);
+    if (T.d) (void)hipFree(T.d);
+    if (T.h) (void)hipHostFree(T.h);
+    T.d = nullptr;
+    T.h = nullptr;
+    T.cap = 0;
+    HIPCHK(c, hipMalloc((void **)&T.d, bytes));
+    HIPCHK(c, hipHostMalloc((void **)&T.h, bytes, hipHostMallocDefault));
+    T.cap = bytes;
+    if (!T.copied) HIPCHK(c, hipEventCreateWithFlags(&T.copied, hipEventDisableTiming));
+    if (!T.used) HIPCHK(c, hipEventCreateWithFlags(&T.used, hipEventDisableTiming));
+    T.used_valid = false;
+  } else if (T.copied) {
+    HIPCHK(c, hipEventSynchronize(T.copied));  // the staging buffer's previous copy (four refreshes ago) has run
+  }
   c->h_tf_eff = c->h_tf_vg;
   if (!c->opt_tf_raw) {
     float alphaScale = (float)(1.0 / sr);
-    for (size_t i = 0; i < n; ++i)
-      c->h_tf_eff[i * 4 + 3] = (unsigned char)(int)((1.0 - pow((1.0 - (c->h_tf_vg[i * 4 + 3] / 255.0)), alphaScale)) * 255);
+    unsigned char map[256];  // NV20VolRen3D::copyScale (:1645-1660) per possible alpha byte
+    for (int a = 0; a < 256; ++a) map[a] = (unsigned char)(int)((1.0 - pow((1.0 - (a / 255.0)), alphaScale)) * 255);
+    for (size_t i = 0; i < n; ++i) c->h_tf_eff[i * 4 + 3] = map[c->h_tf_vg[i * 4 + 3]];
   }
-  if (dev_replace(c, &c->d_tf_vg, c->h_tf_eff.data(), n * 4)) return 1;
+  memcpy(T.h, c->h_tf_eff.data(), n * 4);
   // occupancy bitmap of the effective table: bit (t, s) is set when any of the four texels a
   // bilinear lookup with base texel (s, t) touches has alpha != 0.  A clear bit means the lookup
   // returns alpha == 0 EXACTLY (lerps of zeros), so a kernel may skip the fetch without changing
   // a single bit of the frame.
   {
-    const int sv = c->sv, sg = c->sg, roww = (sv + 31) / 32;
-    std::vector<uint32_t> occ((size_t)roww * sg, 0u);
+    uint32_t *occ = reinterpret_cast<uint32_t *>(T.h + n * 4);
+    memset(occ, 0, occ_words * 4);
+    const unsigned char *e = c->h_tf_eff.data();
     for (int t = 0; t < sg; ++t)
       for (int sx = 0; sx < sv; ++sx) {
         const int s1 = std::min(sx + 1, sv - 1), t1 = std::min(t + 1, sg - 1);
-        const unsigned char *e = c->h_tf_eff.data();
         if (e[((size_t)t * sv + sx) * 4 + 3] | e[((size_t)t * sv + s1) * 4 + 3] | e[((size_t)t1 * sv + sx) * 4 + 3] |
             e[((size_t)t1 * sv + s1) * 4 + 3])
           occ[(size_t)t * roww + (sx >> 5)] |= 1u << (sx & 31);
       }
-    if (dev_replace(c, &c->d_tf_occ, occ.data(), occ.size() * 4)) return 1;
-    c->tf_occ_roww = roww;
   }
+  if (T.used_valid) HIPCHK(c, hipStreamWaitEvent(s, T.used, 0));  // the last frame that read this version is done
+  HIPCHK(c, hipMemcpyAsync(T.d, T.h, bytes, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipEventRecord(T.copied, s));
+  c->tf_cur = v;
+  c->d_tf_vg = reinterpret_cast<uint32_t *>(T.d);
+  c->d_tf_occ = reinterpret_cast<uint32_t *>(T.d + n * 4);
+  c->tf_occ_roww = roww;
   c->tf_rate_applied = sr;
   c->tf_dirty = false;
   return 0;
@@ -806,7 +845,7 @@ extern "C" int smk_get_tf2d_effective(smk_ctx *c, unsigned char *out, float *rat
   smk_raycoef rc;
   double inv[16];
   compute_raycoef(c, &rc, inv);
-  if (refresh_tf2d(c, rc)) return 1;
+  if (refresh_tf2d(c, rc, c->stream)) return 1;
   if (out) memcpy(out, c->h_tf_eff.data(), c->h_tf_eff.size());
   if (rate) *rate = c->tf_rate_applied;
   return 0;
@@ -997,14 +1036,14 @@ extern "C" int smk_last_frame_info(smk_ctx *c, int *kernel, float *ms, double *a
   return 0;
 }
 
-static int build_params(smk_ctx *c, RenderParams &P) {
+static int build_params(smk_ctx *c, RenderParams &P, hipStream_t s) {
   if (!c->have_volume) FAIL(c, "smk_render: no volume uploaded");
   if (!c->have_camera) FAIL(c, "smk_render: no camera set");
   if (c->tf_mode < 0) FAIL(c, "smk_render: no transfer function set");
   memset(&P, 0, sizeof P);
   double inv[16];
   compute_raycoef(c, &P.rc, inv);
-  if (refresh_tf2d(c, P.rc)) return 1;
+  if (refresh_tf2d(c, P.rc, s)) return 1;
   P.vox = c->d_vox;
   P.nrm = c->d_nrm;
   for (int a = 0; a < 3; ++a) {
@@ -1141,10 +1180,10 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
   HIPCHK(c, hipSetDevice(c->device));
   if (!d_rgba) FAIL(c, "smk_render_device: null output");
   RenderParams P;
-  if (build_params(c, P)) return 1;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  if (build_params(c, P, s)) return 1;
   P.out = (float4 *)d_rgba;
   P.depth = (float *)d_depth;
-  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
   // algorithmic bytes: every stored voxel once + TF + RGBA f32 frame
   size_t nst = (size_t)c->D[0] * c->D[1] * c->D[2];
   double bv = c->dtype == SMK_U8 ? (double)c->nelts : 4.0 * c->nelts;
@@ -1205,6 +1244,10 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
     c->last_kernel = 3;
     // per slice the frame buffer (read + write where the slice covers it) and both light buffers move again
     c->last_alg_bytes += (double)sc.nslices * (32.0 * (double)nl);
+    if (c->tf_mode == 1 && c->tf_cur >= 0) {  // this frame read the current table version (refresh_tf2d waits for this before rewriting it)
+      HIPCHK(c, hipEventRecord(c->tfv[c->tf_cur].used, s));
+      c->tfv[c->tf_cur].used_valid = true;
+    }
     c->tcount++;
     return 0;
   }
@@ -1240,11 +1283,16 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
       }
       if (c->tune_state == 4) {  // both timed trials issued: decide once their events have completed
         float ms_s = 0, ms_g = 0;
+        // (a host that enqueues frames far ahead of the GPU would recycle the trials' event pairs -- the ring holds the
+        //  last 64 frames -- before they complete, and the comparison would then be between two later frames of the
+        //  same kernel: wait for the trials rather than let their slots go)
+        if (c->tcount - c->tune_tcount >= SMK_TIMING_RING - 8) (void)hipEventSynchronize(c->tev1[c->tune_slot[1]]);
         if (hipEventQuery(c->tev1[c->tune_slot[0]]) == hipSuccess && hipEventQuery(c->tev1[c->tune_slot[1]]) == hipSuccess &&
             hipEventElapsedTime(&ms_s, c->tev0[c->tune_slot[0]], c->tev1[c->tune_slot[0]]) == hipSuccess &&
             hipEventElapsedTime(&ms_g, c->tev0[c->tune_slot[1]], c->tev1[c->tune_slot[1]]) == hipSuccess) {
           c->tune_choice[sig] = {ms_s <= ms_g ? 2 : 1, c->frame_id + 1024};
           try_slab = ms_s <= ms_g;
+          if (getenv("SMK_DEBUG")) fprintf(stderr, "[smk] auto mode: slice-ring %.3f ms, gather %.3f ms (frame %lld)\n", ms_s, ms_g, c->frame_id);
         }  // else: keep the slice-ring kernel for this frame and ask again
         (void)hipGetLastError();
       } else {
@@ -1295,8 +1343,15 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
   }
   HIPCHK(c, hipEventRecord(c->ev1, s));
   if (trial >= 0) {
-    if (trial >= 2) c->tune_slot[trial - 2] = slot;
+    if (trial >= 2) {
+      c->tune_slot[trial - 2] = slot;
+      c->tune_tcount = c->tcount;
+    }
     c->tune_state = trial + 1;
+  }
+  if (c->tf_mode == 1 && c->tf_cur >= 0) {  // this frame read the current table version (refresh_tf2d waits for this before rewriting it)
+    HIPCHK(c, hipEventRecord(c->tfv[c->tf_cur].used, s));
+    c->tfv[c->tf_cur].used_valid = true;
   }
   c->tcount++;
   return 0;

@@ -82,6 +82,8 @@ struct SlabAux {
     std::vector<int> work;
   } scan[4];
   unsigned scan_next = 0;
+  std::vector<unsigned char> shape_key;  // the small-workgroup shape chosen for this view class (see the launcher's probing pass)
+  int shape_choice = -1, shape_age = 0;
   std::vector<int> plan_work, plan_order;  // the weights the last schedule was built from, and that schedule
   int plan_slots = 0;
   // per-tile workgroup durations of an earlier frame: the schedule's weights
@@ -136,6 +138,15 @@ struct smk_ctx {
   uint32_t *d_tf_vg = nullptr, *d_tf_h = nullptr, *d_tf3d = nullptr;
   uint32_t *d_tf_occ = nullptr;  // occupancy bitmap of the effective (V,G) table, tf_occ_roww words per row
   int tf_occ_roww = 0;
+  // versions of the effective table + bitmap (d_tf_vg / d_tf_occ point into the current one): rebuilt without
+  // stalling the frames in flight when the correction rate moves with the camera (smk_api.hip refresh_tf2d)
+  struct TfVersion {
+    unsigned char *d = nullptr, *h = nullptr;  // device copy; pinned staging
+    size_t cap = 0;
+    hipEvent_t copied = nullptr, used = nullptr;
+    bool used_valid = false;
+  } tfv[4];
+  int tf_cur = -1;
   int sv = 0, sg = 0, s3v = 0, s3g = 0, s3h = 0;
   bool tf_dirty = true;
   float tf_rate_applied = -1.f;
@@ -192,6 +203,7 @@ struct smk_ctx {
   unsigned long long last_slab_sig = 0;  // configuration of the latest slice-ring launch (a failed one is not tried again)
   unsigned long long tune_sig = 0;
   int tune_state = 0, tune_slot[2] = {0, 0};
+  long long tune_tcount = 0;  // frame count when the second timed trial was enqueued
   int last_kernel = 0;
   float last_ms = 0;
   double last_alg_bytes = 0;

@@ -1304,12 +1304,40 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
   // answer depends on the pose: cfg 3's gives 7 / 640, 8 / 640 and 6 / 512 rays, and 1.45 / 1.57 / 1.55 ms).  Two
   // twelve-wave workgroups fill a CU's 24 wave slots at this kernel's 75-80 VGPRs; two ten-wave ones leave four idle.
   // A probing pass sizes the candidates' windows (each scan is kept, see below), the real pass plans the winner.
+  static const bool dbg_time = getenv("SMK_DEBUG_TIME") != nullptr;  // (developer: where the host's planning time goes)
+  static double dbg_t[4] = {0, 0, 0, 0};
+  static int dbg_n = 0;
+  auto dbg_now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+  const double dbg_t0 = dbg_time ? dbg_now() : 0;
+  double dbg_scan = 0;
+  struct DbgExit {
+    bool on; double t0; double *acc; decltype(dbg_now) *now;
+    ~DbgExit() { if (on) *acc += (*now)() - t0; }
+  } dbg_exit{dbg_time, dbg_t0, &dbg_t[2], &dbg_now};
   Cfg cand[3] = {{16, 40, 2}, {40, 16, 2}, {32, 16, 2}};
   const bool choose = opt_tile == 0 && SLAB_BIG_WAVES >= 12;
   int best = -1;
   double best_score = 1e300;
-  for (int pass = choose ? 0 : 1; pass < 2; ++pass) {
-  if (pass == 1 && best >= 0) cfgs[0] = cand[best];
+  // The choice is kept while the view keeps its principal axis, direction and sizes (re-examined every 64 frames): a
+  // camera that moves every frame must not pay the probe -- nor flip between two shapes of nearly equal score, which
+  // would throw away the measured schedule weights of the tiling each time.  The probe itself scans every fourth tile
+  // row and column plus the borders (its answer only ranks the shapes; the real pass sizes the winner's window fully).
+  struct ShapeKey { int as, dir, W, H, dtype, N[3]; float lo[3], hi[3]; } skey;
+  memset(&skey, 0, sizeof skey);
+  skey.as = as; skey.dir = Q.dir; skey.W = P.W; skey.H = P.H; skey.dtype = dtype;
+  for (int a = 0; a < 3; ++a) { skey.N[a] = P.N[a]; skey.lo[a] = P.lo[a]; skey.hi[a] = P.hi[a]; }
+  const bool shape_known = choose && aux->shape_key.size() == sizeof skey && !memcmp(aux->shape_key.data(), &skey, sizeof skey) &&
+                           aux->shape_choice >= 0 && ++aux->shape_age < 64;
+  if (shape_known) best = aux->shape_choice;
+  for (int pass = (choose && !shape_known) ? 0 : 1; pass < 2; ++pass) {
+  if (pass == 1 && best >= 0) {
+    cfgs[0] = cand[best];
+    if (!shape_known) {
+      aux->shape_key.assign(reinterpret_cast<const unsigned char *>(&skey), reinterpret_cast<const unsigned char *>(&skey) + sizeof skey);
+      aux->shape_choice = best;
+      aux->shape_age = 0;
+    }
+  }
   const Cfg *list = pass == 0 ? cand : cfgs;
   const int nlist = pass == 0 ? 3 : ncfg;
   for (int ci = 0; ci < nlist; ++ci) {
@@ -1343,12 +1371,14 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     const bool scan_hit = slot >= 0;
     if (!scan_hit) slot = aux->scan_next++ & 3;
     SlabAux::Scan &scan = aux->scan[slot];
+    const double dbg_s0 = dbg_time ? dbg_now() : 0;
     if (scan_hit) {
       max_eu = scan.v[0]; max_ev = scan.v[1]; max_drift_u = scan.v[2]; max_drift_v = scan.v[3];
       work = scan.work;
     } else
     for (int tyi = 0; tyi < P.nty; ++tyi)
       for (int txi = 0; txi < P.ntx; ++txi) {
+        if (pass == 0 && !(((txi & 3) == 0 || txi == P.ntx - 1) && ((tyi & 3) == 0 || tyi == P.nty - 1))) continue;  // (sparse probe)
         double cA[4][3], cB[4][3];
         for (int c = 0; c < 4; ++c) {
           int cx = std::min(txi * tw + ((c & 1) ? tw - 1 : 0), P.W - 1);
@@ -1390,7 +1420,8 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
           max_ev = std::max(max_ev, vmax - vmin);
         }
       }
-    if (!scan_hit) {  // (a scan that bailed out above returned: only complete ones are kept)
+    if (dbg_time) dbg_scan += dbg_now() - dbg_s0;
+    if (!scan_hit && pass == 1) {  // (a scan that bailed out above returned, a probe is sparse: only complete ones are kept)
       scan.key.assign(reinterpret_cast<const unsigned char *>(&key), reinterpret_cast<const unsigned char *>(&key) + sizeof key);
       scan.v[0] = max_eu; scan.v[1] = max_ev; scan.v[2] = max_drift_u; scan.v[3] = max_drift_v;
       scan.work = work;
@@ -1627,6 +1658,14 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
         aux->plan_slots = slots;
       }
       nblocks = (int)order.size();
+      if (dbg_time) {
+        dbg_t[0] += dbg_scan;
+        dbg_t[1] += dbg_now() - dbg_t0;
+        if (++dbg_n % 60 == 0) {
+          fprintf(stderr, "[smk] planning per frame: scans %.3f ms, all of it up to the launch %.3f ms, whole launcher (previous 60) %.3f ms\n", dbg_t[0] / 60, dbg_t[1] / 60, dbg_t[2] / 60);
+          dbg_t[0] = dbg_t[1] = dbg_t[2] = 0;
+        }
+      }
       if (aux->frame_ev0) {  // the frame's kernel-time bracket opens here: planning is done
         hipError_t e = hipEventRecord(aux->frame_ev0, s);
         if (e != hipSuccess) return e;
