@@ -875,6 +875,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           // for most of the consumers' iteration
           int pbn = pb;
           if (act) pbn = (m + 1 <= m1) ? __mul24(psgn, base_slice(m + 1)) + poff : SLAB_DONE;
+          // (every turn: on the 5-slot ring a progress word that is one turn late costs 16 % -- 4.07 vs 4.71 ms)
           const int plo = wave_min_i32(pbn);
           if (plo != pos && plo < SLAB_DONE) {
             pos = plo;
@@ -1481,7 +1482,6 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     const size_t fixed = (size_t)Q.Ds * sizeof(SlabEnt) + (8 + 32) * 4 + 64 + (Q.use_ah ? (size_t)P.sv * 4 : 0) + (Q.use_occ ? occ_bytes : 0);
     // ring: as many slots as fit two workgroups per CU (small tiles) or one (big tiles)
     size_t budget = (nw + nl) > SLAB_BIG_WAVES ? 158 * 1024 : 78 * 1024;
-    if (const char *e = getenv("SMK_LDS_BUDGET_KB")) budget = (size_t)atoi(e) * 1024;  // (experiment)
     if (budget <= fixed) { *why = "slice table does not fit LDS"; return hipErrorNotSupported; }
     int ns = (int)((budget - fixed) / (size_t)Q.slot_bytes);
     if (ns > 24) ns = 24;
@@ -1511,8 +1511,8 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     // (re-measured with two slices in flight per loader, 5 slots: wstep 0 / 1 / 2 -> 3.80 / 3.68 / 4.68 ms)
     Q.wstep = std::max(0, std::min((int)ceil(fabs(Bc[as])), ns - 4));
     if (opt_T > 0) Q.wstep = std::max(0, std::min(opt_T - 1, ns - 3));  // (experiment knob: slab_T = wstep + 1)
+    // (small workgroups, 10 slots against a band of 4: every other turn 1.87 ms, every turn 1.90, every 4th / 8th 2.0 / 2.2)
     Q.pmask = ns >= 2 * band ? 1 : 0;
-    if (const char *e = getenv("SMK_PMASK")) Q.pmask = atoi(e);  // (experiment)
     const size_t lds = (size_t)ns * Q.slot_bytes + fixed;
     if (getenv("SMK_DEBUG"))
       fprintf(stderr, "[smk] slice-ring plan: tile %dx%d, %d+%d waves, window %d units x %d rows (pitch %d units), %d chunks/slice, %d slots of %d B, table+ctl %zu B, LDS %zu B, band %d, wstep %d, pmask %d, maxfly %d\n",
