@@ -369,6 +369,15 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
     float sc = smk_clampf(s, 0.0f, (float)(NS - 1));
     return min((int)sc, NS - 2);
   };
+  // the same, also handing out the clamped coordinate: exactly smk_lin_clamp's (xc, i0) of the principal axis, which the
+  // sample of plane q needs again one loop turn later (carried instead of recomputed: 4 VALU per turn; within noise on both frames)
+  auto base_slice_c = [&](int q, float &sc_out) -> int {
+    float s = __fmaf_rn((float)q, B[AS], A[AS]);
+    sc_out = smk_clampf(s, 0.0f, (float)(NS - 1));
+    return min((int)sc_out, NS - 2);
+  };
+  float car_sc = 0.f;  // clamped principal-axis coordinate and base slice of THIS ray's next sample (plane m)
+  int car_i = 0;
 
   // ---- workgroup slice range
   if (tid == 0) {
@@ -472,7 +481,10 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   // every consumer wave announces the first position it needs before anyone moves on
   const int psgn = dir > 0 ? 1 : -1, poff = dir > 0 ? -smin : smax;  // position of base slice b = psgn*b + poff
   int pb = SLAB_DONE;  // position of this ray's next sample
-  if (m <= m1) pb = psgn * base_slice(m) + poff;
+  if (m <= m1) {
+    car_i = base_slice_c(m, car_sc);
+    pb = psgn * car_i + poff;
+  }
   int pos = SLAB_DONE;
   if (!is_loader && npos > 0) {
     pos = wave_min_i32(pb);
@@ -850,6 +862,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
         float fx = 0.f, fy = 0.f, fz = 0.f;
         unsigned a0 = 0, b0 = 0;
         typename std::conditional<DT == 0, v2u, v4f>::type rq[EARLY ? 8 : 1];
+        float early_nsc = 0.f;
+        int early_ni = 0;
         const bool work = act && !stream_only;
         if (work) {
           // the two slices' slot images (one 8-byte table entry each, adjacent): issued first,
@@ -857,12 +871,17 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           const int *te = reinterpret_cast<const int *>(smem + (wtab_addr - ring_addr)) + 2 * (__mul24(psgn, pb) + eoff);  // (24-bit multiply: full rate; |pb| < 4096 on a lane that works)
           const int base_a = te[0], base_b = te[2];
           const float mf = (float)m;
-          const float p0 = __fmaf_rn(mf, B[0], A[0]), p1 = __fmaf_rn(mf, B[1], A[1]), p2 = __fmaf_rn(mf, B[2], A[2]);
           // (no membership test: [m, m1] is exactly the inside interval, see the set-up)
-          int x0, x1, y0, y1, z0, z1;
-          smk_lin_clamp(p0, P.N[0], x0, x1, fx);
-          smk_lin_clamp(p1, P.N[1], y0, y1, fy);
-          smk_lin_clamp(p2, P.N[2], z0, z1, fz);
+          // (the principal axis' clamped coordinate and base index were computed when this sample's position in
+          //  the stream was: fma(m, B, A) -> clamp -> min((int), N - 2), the very operations of smk_lin_clamp)
+          int x0 = 0, x1, y0 = 0, y1, z0 = 0, z1;
+          if constexpr (AS != 0) smk_lin_clamp(__fmaf_rn(mf, B[0], A[0]), P.N[0], x0, x1, fx);
+          else { x0 = car_i; fx = car_sc - (float)car_i; }
+          if constexpr (AS != 1) smk_lin_clamp(__fmaf_rn(mf, B[1], A[1]), P.N[1], y0, y1, fy);
+          else { y0 = car_i; fy = car_sc - (float)car_i; }
+          if constexpr (AS != 2) smk_lin_clamp(__fmaf_rn(mf, B[2], A[2]), P.N[2], z0, z1, fz);
+          else { z0 = car_i; fz = car_sc - (float)car_i; }
+          (void)x1; (void)y1; (void)z1;
           const int iu = AU == 0 ? x0 : y0, iv = AV == 1 ? y0 : z0;  // global voxel indices
           const unsigned lo_off = __umul24((unsigned)iv, pitch_b) + ((unsigned)iu << VBL);  // (24-bit multiply: full rate)
           a0 = (unsigned)base_a + lo_off;
@@ -874,7 +893,16 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           // a classification + shading later -- on a 5-slot ring the loaders otherwise sit blocked
           // for most of the consumers' iteration
           int pbn = pb;
-          if (act) pbn = (m + 1 <= m1) ? __mul24(psgn, base_slice(m + 1)) + poff : SLAB_DONE;
+          float nsc = car_sc;
+          int ni = car_i;
+          if (act) {
+            if (m + 1 <= m1) {
+              ni = base_slice_c(m + 1, nsc);
+              pbn = __mul24(psgn, ni) + poff;
+            } else pbn = SLAB_DONE;
+          }
+          early_nsc = nsc;
+          early_ni = ni;
           // (every turn: on the 5-slot ring a progress word that is one turn late costs 16 % -- 4.07 vs 4.71 ms)
           const int plo = wave_min_i32(pbn);
           if (plo != pos && plo < SLAB_DONE) {
@@ -963,7 +991,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             // occupancy bit of the texel quad (LDS): clear => alpha is exactly 0, no fetch.  Most
             // samples of a typical transfer function end here, without the L2 round trip.
             bool maybe = true;
-            if (Q.use_occ) maybe = (occ[t0 * P.occ_roww + (s0 >> 5)] >> (s0 & 31)) & 1u;
+            if (Q.use_occ) maybe = (occ[__mul24(t0, P.occ_roww) + (s0 >> 5)] >> (s0 & 31)) & 1u;
             col.w = 0.0f;
             if (maybe) {
               // alpha first (all four (V,G) texels are needed for it anyway); colour only on a hit
@@ -1028,7 +1056,18 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
         }
         if (act) {
           ++m;
-          pb = (m <= m1) ? __mul24(psgn, base_slice(m)) + poff : SLAB_DONE;
+          if constexpr (EARLY) {
+            // (the next sample's slice was worked out when the ring slots were released; m1 may since have shrunk to m - 1
+            //  -- the ray saturated -- which ends it)
+            if (m <= m1) {
+              car_sc = early_nsc;
+              car_i = early_ni;
+              pb = __mul24(psgn, car_i) + poff;
+            } else pb = SLAB_DONE;
+          } else if (m <= m1) {
+            car_i = base_slice_c(m, car_sc);
+            pb = __mul24(psgn, car_i) + poff;
+          } else pb = SLAB_DONE;
         }
         if (count) {
           n_it += 1.f;
