@@ -1252,10 +1252,10 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
     return 0;
   }
   // ---- auto mode: which kernel for this configuration?
-  bool try_slab = c->opt_kernel != 1 && (c->tf_mode == 1 || c->tf_mode == 2);
+  bool try_slab = c->opt_kernel != 1;
   unsigned long long sig = 0;
   int trial = -1;  // 0 / 1: this frame is the slice-ring / gather trial of a new configuration
-  if (c->opt_kernel == 0 && (c->tf_mode == 1 || c->tf_mode == 2)) {
+  if (c->opt_kernel == 0) {
     int as = 0;
     for (int a = 1; a < 3; ++a)
       if (fabsf(P.rc.Bc[a]) > fabsf(P.rc.Bc[as])) as = a;

@@ -1017,7 +1017,9 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
               col.z = slab_tex_chan(tx4, 2);
             }
             float4 src;
-            if (SH == 0) {
+            if (TF == 0) {
+              src = col;  // the 1-D colour table's entries are premultiplied (TLUT.cpp:65-71), as in the gather kernel
+            } else if (SH == 0) {
               src = smk_shade_sample<0>(P, col, 0.f, 0.f, 0.f, 0.f);
             } else {
               uint32_t nb[8];  // the packed normals of the same corners: second batch, or already here (EARLY)
@@ -1265,7 +1267,9 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
   const int opt_sched = (opt_T >> 24) & 0xf;  // (experiment knob: order of an XCD's tiles, see the schedule)
   opt_T &= 0xff;
   *why = nullptr;
-  if (tf_mode != 1 && tf_mode != 2) { *why = "1-D colour table (scalar volumes: gather kernel)"; return hipErrorNotSupported; }
+  if (tf_mode < 0 || tf_mode > 2) { *why = "no classification mode"; return hipErrorNotSupported; }
+  if (tf_mode == 0 && (!P.tlut || P.tlut_size < 1)) { *why = "no colour table"; return hipErrorNotSupported; }
+  if (tf_mode == 0) shade_kind = 0;  // (the scalar renderer does not shade, VolumeRenderer.cpp:576-587)
   if (tf_mode == 2 && (!P.tf3d || P.s3v < 1 || P.s3g < 1 || P.s3h < 1)) { *why = "no 3-D table"; return hipErrorNotSupported; }
   if (P.pert_on) { *why = "perturbation"; return hipErrorNotSupported; }
   if (P.blend == SMK_BLEND_BACK_TO_FRONT) { *why = "back-to-front blend (slices stream front to back)"; return hipErrorNotSupported; }
@@ -1784,6 +1788,12 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
       if constexpr ((N == 8 && L == 2) || (N == 10 && L == 2) || (N == 12 && L == 4))                \
         return after_launch(launch_slab<D, S, R, N, L, false, 2>(P, Q, lds, nblocks, s));            \
       *why = "no dense-3-D-table instance for this tile size";                                       \
+      return hipErrorNotSupported;                                                                   \
+    }                                                                                                \
+    if (tf_mode == 0) {                                                                              \
+      if constexpr (S == 0 && ((N == 8 && L == 2) || (N == 10 && L == 2) || (N == 12 && L == 4)))    \
+        return after_launch(launch_slab<D, S, R, N, L, false, 0>(P, Q, lds, nblocks, s));            \
+      *why = "no colour-table instance for this tile size";                                          \
       return hipErrorNotSupported;                                                                   \
     }                                                                                                \
     if constexpr (D == 1 && S == 1) {                                                                \

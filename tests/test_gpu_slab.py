@@ -141,12 +141,28 @@ def test_sharded_regions(gpu_renderer_factory, smk, world):
 
 
 def test_forced_slab_reports_why_it_cannot_run(R, smk):
-    sc = make_scene("cfg1")          # scalar volume, 1-D colour table: the gather kernel's alone
+    sc = make_scene("cfg3", pert=True)          # a perturbed fetch leaves every staged window: the gather kernel's alone
     push_scene(R, sc)
     R.set_option("kernel", 2)
-    with pytest.raises(smk.SmkError, match="gather-only|not applicable"):
+    with pytest.raises(smk.SmkError, match="not applicable"):
         R.render()
     R.set_option("kernel", 0)
+    R.set_perturb(None, None, None)
+
+
+@pytest.mark.parametrize("pose", ["id", "rot", "back", "side", "x+", "y-"])
+def test_scalar_volume_with_the_1d_colour_table(R, pose):
+    """cfg 1 -- VolumeRenderer's own case (u8 scalar, post-filter colour table, VolumeRenderer.cpp:576-587) -- on the
+    slice-ring kernel: bit-identical to the gather kernel, <= 1e-4 from the checker; also as a float volume"""
+    sc = make_scene("cfg1", n=32, size=72, steps=80, pose=pose)
+    ref = sc.render()
+    a, b = _both(R, sc)
+    assert ref[..., 3].max() > 0.05
+    assert np.array_equal(a, b) and np.abs(b - ref).max() <= TOL
+    scf = make_scene("cfg1", n=32, size=72, steps=80, pose=pose)
+    scf.data = (scf.data.astype(np.float32) / np.float32(255)).astype(np.float32)
+    a, b = _both(R, scf)
+    assert np.array_equal(a, b) and np.abs(b - scf.render()).max() <= TOL
 
 
 def test_byte_offsets_beyond_4_gib_inside_a_slice_stride(gpu_renderer_factory):
