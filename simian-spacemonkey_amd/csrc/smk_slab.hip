@@ -1299,6 +1299,8 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
   if (Q.perm == 0) { Q.strideV = P.D[0]; Q.strideS = (long long)P.D[0] * P.D[1]; Q.vox = vox_native; }
   else if (Q.perm == 1) { Q.strideV = (long long)P.D[0] * P.D[1]; Q.strideS = P.D[0]; Q.vox = vox_native; }
   else { Q.strideV = P.D[1]; Q.strideS = (long long)P.D[1] * P.D[2]; Q.vox = vox_xmajor; }  // [x][z][y]
+  // (the test as a run-time branch in the consumers was built and measured: frames identical to the gather kernel's, but
+  //  every frame WITHOUT a clip plane paid 4-5 % at 512^3 and 2 % at 1024^3 for the scalar registers it holds)
   if (P.cplane_on) { *why = "free clip plane (a per-sample half-space test: gather kernel)"; return hipErrorNotSupported; }
   // an empty region (a clip plane outside a shard's box): the gather kernel's explicit comparisons
   // render it as nothing; the median-of-three membership test here needs lo <= hi
