@@ -264,7 +264,6 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 #endif
   constexpr int NLG = !SLAB_ALT ? 1 : (EARLY ? ((NL % SLAB_BIG_NLG) == 0 ? SLAB_BIG_NLG : 1) : NL);
   constexpr int LPG = NL / NLG;
-  constexpr bool ALT = NLG > 1;
   constexpr int QSTEP = NLG;
   extern __shared__ __align__(16) unsigned char smem[];
   // LDS carve: ring [nslots][slot_bytes] | slice table [Ds] | control words | alpha_H
@@ -1160,8 +1159,64 @@ int slab_clip_polygon(const SlabVec *in, int n, const double pl[4], SlabVec *out
   return m;
 }
 
+bool slab_bundle_slice_range_exact(const RenderParams &P, double fx0, double fy0, double fx1, double fy1, int as, double *smin,
+                                   double *smax);
+// The common case without clipping: when the four corner rays enter the box through ONE face and leave it through ONE
+// face (inside the sampled plane range), so does every ray between them -- the rays through a face form a convex set --
+// and bundle /\ box is the hexahedron of the four entry and four exit points: its S-extent is theirs.  (A bundle that
+// contains a box edge or vertex, or is cut by the first / last sample plane, goes the exact way below.)
+static bool slab_bundle_slice_range_fast(const RenderParams &P, double fx0, double fy0, double fx1, double fy1, int as, double *smin,
+                                         double *smax) {
+  const smk_raycoef &rc = P.rc;
+  const double fx[4] = {fx0, fx1, fx1, fx0}, fy[4] = {fy0, fy0, fy1, fy1};
+  const double q0 = -0.5, q1 = (double)(rc.nplanes - 1) + 0.5, eps = 1e-3;
+  int fin = -1, fout = -1;
+  double mn = 1e300, mx = -1e300;
+  for (int c = 0; c < 4; ++c) {
+    const double px = fx[c] * (double)rc.pxs + (double)rc.pxl, py = fy[c] * (double)rc.pys + (double)rc.pyl;
+    double A[3], B[3], te = -1e300, tx = 1e300;
+    int ie = -1, ix = -1;
+    for (int a = 0; a < 3; ++a) {
+      A[a] = px * rc.Ax[a] + py * rc.Ay[a] + rc.Ac[a];
+      B[a] = px * rc.Bx[a] + py * rc.By[a] + rc.Bc[a];
+      const double lo = (double)P.lo[a] - eps, hi = (double)P.hi[a] + eps;
+      if (fabs(B[a]) < 1e-12) {
+        if (A[a] < lo || A[a] > hi) return false;
+        continue;
+      }
+      const double t1 = (lo - A[a]) / B[a], t2 = (hi - A[a]) / B[a];
+      const double tn = t1 < t2 ? t1 : t2, tf = t1 < t2 ? t2 : t1;
+      if (tn > te) { te = tn; ie = 2 * a + (t1 < t2 ? 0 : 1); }
+      if (tf < tx) { tx = tf; ix = 2 * a + (t1 < t2 ? 1 : 0); }
+    }
+    if (!(te < tx) || te < q0 || tx > q1 || ie < 0 || ix < 0) return false;
+    if (c == 0) { fin = ie; fout = ix; }
+    else if (ie != fin || ix != fout) return false;
+    const double se = A[as] + te * B[as], sx = A[as] + tx * B[as];
+    mn = std::min(mn, std::min(se, sx));
+    mx = std::max(mx, std::max(se, sx));
+  }
+  *smin = std::max(mn, (double)P.lo[as]);
+  *smax = std::min(mx, (double)P.hi[as]);
+  return true;
+}
+
 bool slab_bundle_slice_range(const RenderParams &P, double fx0, double fy0, double fx1, double fy1, int as, double *smin,
                              double *smax) {
+  static const int check = getenv("SMK_DEBUG_SCAN") ? atoi(getenv("SMK_DEBUG_SCAN")) : 0;  // (developer: 1 = compare the short way with the exact one, 2 = exact only)
+  if (check != 2 && slab_bundle_slice_range_fast(P, fx0, fy0, fx1, fy1, as, smin, smax)) {
+    if (!check) return true;
+    double a = 0, b = 0;
+    const bool ok = slab_bundle_slice_range_exact(P, fx0, fy0, fx1, fy1, as, &a, &b);
+    if (!ok || fabs(a - *smin) > 5e-3 || fabs(b - *smax) > 5e-3)  // (the exact way pads its clipping planes by 1e-6 of the scene's scale)
+      fprintf(stderr, "[smk] SCAN MISMATCH tile (%g,%g)-(%g,%g): fast [%.9g, %.9g] exact %d [%.9g, %.9g]\n", fx0, fy0, fx1, fy1, *smin, *smax, (int)ok, a, b);
+    return true;
+  }
+  return slab_bundle_slice_range_exact(P, fx0, fy0, fx1, fy1, as, smin, smax);
+}
+
+bool slab_bundle_slice_range_exact(const RenderParams &P, double fx0, double fy0, double fx1, double fy1, int as, double *smin,
+                                   double *smax) {
   const smk_raycoef &rc = P.rc;
   const double fx[4] = {fx0, fx1, fx1, fx0}, fy[4] = {fy0, fy0, fy1, fy1};  // cyclic
   const double q0 = -0.5, q1 = (double)(rc.nplanes - 1) + 0.5;
