@@ -1604,7 +1604,9 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     // ~7 KiB per CU).  Measured (frames per setting 5/4/3/2/1 on a 5-slot ring): 1024^3 f32 4.27 /
     // 4.19 / 4.03 / 3.84 / 4.36 ms; 512^3 f32 (12 slots) 1.81 at 12, 1.66 at 2-4, 1.80 at 1; 1024^3 u8
     // 3.54 -> 2.94 ms.
-    Q.maxfly = std::max(1, std::min(std::min(ns, 63 / mych + 1), opt_fly > 0 ? opt_fly : 2));
+    // (small workgroups since their loaders take whole slices in turn: ONE slice in flight per loader -- the other
+    //  loader's is in flight beside it; 1 / 2: cfg 3 1.42-1.44 / 1.45-1.46 ms, other poses and a 256^3 frame -0.3 to -3 %)
+    Q.maxfly = std::max(1, std::min(std::min(ns, 63 / mych + 1), opt_fly > 0 ? opt_fly : (nlg > 1 && (nw + nl) <= SLAB_BIG_WAVES ? 1 : 2)));
     // a deep ring lets the whole band step together (every lane active); on a short one a wave that
     // waits for its whole band leaves the loaders nothing to overlap with (measured, 1024^3: 5 slots,
     // wstep 0 / 1 / 2 -> 5.5 / 5.8 / 6.8 ms)
