@@ -360,15 +360,24 @@ def extra_legs(r, frame, work, steps):
     r.upload_volume_device(merged.data_ptr(), (n, n, n), 3, 0, mnrm.data_ptr(), dmode="V2G")
     del merged, mnrm
     torch.cuda.empty_cache()
-    rng = np.random.default_rng(5)
-    t3 = rng.integers(0, 256, (16, 16, 16, 4), dtype=np.uint8)
-    t3[..., 3] = (t3[..., 3].astype(np.float32) * 0.25).astype(np.uint8)
+    # the dense (v, g, h) table at the reference's own size, 256 x 256 x 4 "panes" (TFWidgetRen.cpp:98-100): cfg 3's
+    # LevWidget table in every pane, opacity scaled per pane the way the widgets' boundary emphasis does for every
+    # sheet but the second (LevWidget.cpp:704-761)
+    if os.environ.get("SMK_BENCH_CFG5_TABLE") == "random16":   # (round 1's table: 16^3 random colours, every sample visible)
+        rng = np.random.default_rng(5)
+        t3 = rng.integers(0, 256, (16, 16, 16, 4), dtype=np.uint8)
+        t3[..., 3] = (t3[..., 3].astype(np.float32) * 0.25).astype(np.uint8)
+    else:
+        pane = np.load(os.path.join(g, "tf_cfg3_levwidget.npy"))
+        t3 = np.stack([pane] * 4).copy()
+        for h_, be in enumerate((0.4, 1.0, 0.7, 0.4)):
+            t3[h_, ..., 3] = (pane[..., 3].astype(np.float32) * be).astype(np.uint8)
     r.set_option("tf_raw", 1)
     r.set_tf3d(t3)
     r.set_camera(modelview(xform, (1.0, 1.0, 1.0)), FRUSTUM, (1.0, 20.0), 1024, 1024)
     r.set_sampling(0.0, 1024, 1.0, 1)
     r.set_shading("r8k", LIGHT, EYE, AT, xf, INTENS)
-    run("cfg5_unperturbed", 1024, 1024, "cfg5 without the perturbation: 2 x 512^3 u8 fields merged (V2G), dense 3-D table, R8k Phong, 1024x1024x1024")
+    run("cfg5_unperturbed", 1024, 1024, "cfg5 without the perturbation: 2 x 512^3 u8 fields merged (V2G), dense 3-D table %dx%dx%d, R8k Phong, 1024x1024x1024" % (t3.shape[2], t3.shape[1], t3.shape[0]))
     r.set_perturb(libc_noise_tex(32), (.02, .01, 0, 0), (.2, 2.1, 4.5, 8.7))
     run("cfg5", 1024, 1024, "cfg5: the same with the noise-perturbed fetch (32^3 noise, weights .02/.01, scales .2/2.1): gather kernel")
     r.set_perturb(None, None, None)

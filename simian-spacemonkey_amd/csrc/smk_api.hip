@@ -83,7 +83,7 @@ extern "C" void smk_destroy(smk_ctx *c) {
     if (T.copied) (void)hipEventDestroy(T.copied);
     if (T.used) (void)hipEventDestroy(T.used);
   }
-  void *ptrs[] = {c->d_tlut, c->d_tf_h, c->d_tf3d, c->d_noise, c->d_out, c->d_depth, c->d_light[0], c->d_light[1]};
+  void *ptrs[] = {c->d_tlut, c->d_tf_h, c->d_tf3d, c->d_tf3d_occ, c->d_noise, c->d_out, c->d_depth, c->d_light[0], c->d_light[1]};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->slab.h_status) (void)hipHostFree(c->slab.h_status);
@@ -381,6 +381,26 @@ extern "C" int smk_set_tf3d(smk_ctx *c, const unsigned char *ptex, int sv, int s
   HIPCHK(c, hipSetDevice(c->device));
   if (!ptex || sv < 1 || sg < 1 || sh < 1) FAIL(c, "smk_set_tf3d: bad table");
   if (dev_replace(c, &c->d_tf3d, ptex, (size_t)sv * sg * sh * 4)) return 1;
+  // occupancy of the dense table, folded over its third axis: bit (t, s) is set when ANY sheet has a non-zero alpha in
+  // the 2 x 2 texel quad based at (s, t).  A clear bit means the trilinear lookup of every sample whose (v, g) base texel
+  // is (s, t) returns alpha == 0 exactly, whatever its third coordinate -- the kernels skip the eight-texel gather then
+  // (the reference's widgets paint a few regions of a 256 x 256 x 4 table: most of it is transparent)
+  {
+    const int roww = (sv + 31) / 32;
+    std::vector<uint32_t> occ((size_t)roww * sg, 0u);
+    for (int t = 0; t < sg; ++t)
+      for (int sx = 0; sx < sv; ++sx) {
+        const int s1 = std::min(sx + 1, sv - 1), t1 = std::min(t + 1, sg - 1);
+        unsigned any = 0;
+        for (int h = 0; h < sh && !any; ++h) {
+          const unsigned char *e = ptex + (size_t)h * sg * sv * 4;
+          any = e[((size_t)t * sv + sx) * 4 + 3] | e[((size_t)t * sv + s1) * 4 + 3] | e[((size_t)t1 * sv + sx) * 4 + 3] | e[((size_t)t1 * sv + s1) * 4 + 3];
+        }
+        if (any) occ[(size_t)t * roww + (sx >> 5)] |= 1u << (sx & 31);
+      }
+    if (dev_replace(c, &c->d_tf3d_occ, occ.data(), occ.size() * 4)) return 1;
+    c->tf3d_occ_roww = roww;
+  }
   c->s3v = sv;
   c->s3g = sg;
   c->s3h = sh;
@@ -401,8 +421,7 @@ extern "C" int smk_set_camera(smk_ctx *c, const double mv[16], const float fr[4]
   memcpy(c->clip, clip, sizeof c->clip);
   c->W = w;
   c->H = h;
-  c->have_camera = true;
-  c->tf_dirty = true;  // steps-mode opacity correction depends on the view-depth extent
+  c->have_camera = true;  // (steps-mode opacity correction follows the view-depth extent: refresh_tf2d compares the rate itself)
   return 0;
 }
 
@@ -1092,8 +1111,8 @@ static int build_params(smk_ctx *c, RenderParams &P, hipStream_t s) {
   P.tlut_size = c->tlut_size;
   P.tf_vg = c->d_tf_vg;
   P.tf_h = c->d_tf_h;
-  P.tf_occ = c->tf_mode == 1 ? c->d_tf_occ : nullptr;
-  P.occ_roww = c->tf_occ_roww;
+  P.tf_occ = c->tf_mode == 1 ? c->d_tf_occ : c->tf_mode == 2 ? c->d_tf3d_occ : nullptr;
+  P.occ_roww = c->tf_mode == 2 ? c->tf3d_occ_roww : c->tf_occ_roww;
   P.sv = c->sv;
   P.sg = c->sg;
   // third-axis data modes (NV20VolRen3D.cpp:686-693, 813-819)

@@ -136,6 +136,8 @@ struct smk_ctx {
   int tlut_size = 0;
   std::vector<unsigned char> h_tf_vg, h_tf_h, h_tf_eff;
   uint32_t *d_tf_vg = nullptr, *d_tf_h = nullptr, *d_tf3d = nullptr;
+  uint32_t *d_tf3d_occ = nullptr;  // occupancy of the dense 3-D table folded over its third axis (smk_set_tf3d)
+  int tf3d_occ_roww = 0;
   uint32_t *d_tf_occ = nullptr;  // occupancy bitmap of the effective (V,G) table, tf_occ_roww words per row
   int tf_occ_roww = 0;
   // versions of the effective table + bitmap (d_tf_vg / d_tf_occ point into the current one): rebuilt without

@@ -433,7 +433,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       for (int e = tid; e < P.sv; e += NTH) ah[e] = smk_ub(P.tf_h[e], 3);
     if (Q.use_occ) {
       uint32_t *occ_w = const_cast<uint32_t *>(occ);
-      for (int e = tid; e < P.occ_roww * P.sg; e += NTH) occ_w[e] = P.tf_occ[e];
+      for (int e = tid; e < P.occ_roww * (TF == 2 ? P.s3g : P.sg); e += NTH) occ_w[e] = P.tf_occ[e];
     }
     const int wuv = Q.wu * UPV;  // window width in voxels
     for (int q = tid; q <= npos; q += NTH) {
@@ -1005,6 +1005,16 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
               col.w = smk_sat(col.w);
             }
             hit = col.w != 0.0f;
+          } else if (TF == 2 && Q.use_occ) {
+            // dense 3-D table: the (v, g) base texel's occupancy bit, folded over the sheets (smk_set_tf3d), decides
+            // whether the eight-texel gather can return anything but alpha == 0
+            int s0, s1, t0, t1;
+            float fs, ft;
+            smk_lin_clamp(__fmaf_rn(ch0, (float)P.s3v, -0.5f), P.s3v, s0, s1, fs);
+            smk_lin_clamp(__fmaf_rn(ch1, (float)P.s3g, -0.5f), P.s3g, t0, t1, ft);
+            col.w = 0.0f;
+            hit = false;
+            if ((occ[__mul24(t0, P.occ_roww) + (s0 >> 5)] >> (s0 & 31)) & 1u) hit = smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col);
           } else {
             hit = smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col);
           }
@@ -1574,11 +1584,11 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
 
     Q.use_ah = (tf_mode == 1 && P.third_axis && P.nelts <= 3 && P.sv >= 2 && P.sv <= 2048) ? 1 : 0;
     if (tf_mode == 1 && (P.sv < 2 || P.sg < 2)) { *why = "transfer function smaller than 2x2"; return hipErrorNotSupported; }
-    const size_t occ_bytes = tf_mode == 1 ? (size_t)P.occ_roww * P.sg * 4 : 0;
+    const size_t occ_bytes = tf_mode == 1 ? (size_t)P.occ_roww * P.sg * 4 : tf_mode == 2 ? (size_t)P.occ_roww * P.s3g * 4 : 0;
     Q.fast_tf = (tf_mode == 1 && (!P.third_axis || Q.use_ah)) ? 1 : 0;
     // (measured: 5.99 -> 5.61 ms on 1024^3, where the texel gathers share the texture path with a
     //  heavy stream; no gain at 512^3, where the 8 KB are worth more as ring slots)
-    Q.use_occ = (Q.fast_tf && Q.mask_need && P.tf_occ && occ_bytes > 0 && occ_bytes <= 8192) ? 1 : 0;
+    Q.use_occ = ((Q.fast_tf || tf_mode == 2) && Q.mask_need && P.tf_occ && occ_bytes > 0 && occ_bytes <= 8192) ? 1 : 0;
     const size_t fixed = (size_t)Q.Ds * sizeof(SlabEnt) + (8 + 32) * 4 + 64 + (Q.use_ah ? (size_t)P.sv * 4 : 0) + (Q.use_occ ? occ_bytes : 0);
     // ring: as many slots as fit two workgroups per CU (small tiles) or one (big tiles)
     size_t budget = (nw + nl) > SLAB_BIG_WAVES ? 158 * 1024 : 78 * 1024;

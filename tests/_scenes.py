@@ -59,6 +59,19 @@ def tf3d_dense(n=16, seed=5):
     return t
 
 
+def tf3d_panes():
+    """the reference's dense-table shape: 256 x 256 x 4 sheets (TFWidgetRen.cpp:98-100), here cfg 3's widgets in every
+    sheet with the opacity scaled per sheet -- mostly transparent, which is what the kernels' occupancy shortcut lives on"""
+    pane = tf_cfg3()
+    t = np.stack([pane] * 4).copy()
+    for h, be in enumerate((0.4, 1.0, 0.7, 0.4)):
+        t[h, ..., 3] = (pane[..., 3].astype(np.float32) * be).astype(np.uint8)
+    t[2, :40, :40, 3] = 0          # (a region only SOME sheets paint: the bit must stay set there)
+    t[0, 200:, 200:, 3] = 90       # (... and one only the first sheet paints)
+    t[3, :, 60:110, 3] = np.maximum(t[3, :, 60:110, 3], 70)   # (... and a band of values only the LAST sheet paints everywhere)
+    return t
+
+
 # principal axis / marching direction coverage for the slice-ring kernel: views roughly along
 # +-z, +-y, +-x (the last needs the x-major copy), each a little off-axis
 POSES = {
@@ -96,6 +109,9 @@ def make_scene(kind, n=32, size=48, steps=48, pose="rot", f32=False, shade=0, th
         elif kind == "tf3d":
             sc.tf_mode = 2
             sc.tf3d = tf3d_dense()
+        elif kind == "tf3d_panes":
+            sc.tf_mode = 2
+            sc.tf3d = tf3d_panes()
         sc.third_axis = 1 if third else 0
         if third and sc.tf_h is None:
             sc.tf_h = tf_h(0.5)

@@ -71,6 +71,15 @@ def test_dense_tf3d(R, f32):
     _check(R, make_scene("tf3d", f32=f32, shade=1))
 
 
+@pytest.mark.parametrize("pert", [False, True])
+def test_sparse_3d_table_of_the_references_shape(R, pert):
+    """256 x 256 x 4 sheets, mostly transparent: the occupancy shortcut (a folded bit per (v, g) texel quad) skips
+    lookups without changing a bit -- with the perturbed fetch this is BASELINE config 5's classification"""
+    sc = make_scene("tf3d_panes", shade=1, pert=pert, third=True)
+    _check(R, sc)
+    assert (sc.render()[..., 3] > 0).mean() > 0.2
+
+
 def test_perturbation(R):
     _check(R, make_scene("cfg3", pert=True, shade=1))
 

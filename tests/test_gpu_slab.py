@@ -41,7 +41,8 @@ def test_every_axis_and_direction(R, pose, f32):
 
 
 @pytest.mark.parametrize("kind,shade,f32", [("cfg2", 0, True), ("cfg3", 1, True), ("cfg3", 2, True), ("cfg4", 0, True),
-                                             ("tf3d", 1, True), ("tf3d", 0, False), ("tf3d", 2, False)])
+                                             ("tf3d", 1, True), ("tf3d", 0, False), ("tf3d", 2, False),
+                                             ("tf3d_panes", 1, True), ("tf3d_panes", 1, False), ("tf3d_panes", 0, True)])
 def test_modes(R, kind, shade, f32):
     """2-D table, 2-D x third axis, and the dense 3-D (v,g,h) table of BASELINE configs 4/5 on the slice-ring kernel"""
     sc = make_scene(kind, n=32, size=64, steps=64, pose="diag", f32=f32, shade=shade)
