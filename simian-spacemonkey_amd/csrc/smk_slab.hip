@@ -240,14 +240,18 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   constexpr int VBL = DT == 0 ? 3 : 4;   // log2
   constexpr int NTH = (NW + NL) * 64;
   // big workgroups (one per CU, 128 VGPRs each): read whole voxels, release ring slots early
-  constexpr bool EARLY = (NW + NL) > SLAB_BIG_WAVES;
+#ifndef SLAB_EARLY
+#define SLAB_EARLY 1  // (re-measured with the loaders in pairs: without the early release 4.56 vs 4.11 ms on the 1024^3 frame)
+#endif
+  constexpr bool BIG = (NW + NL) > SLAB_BIG_WAVES;
+  constexpr bool EARLY = BIG && SLAB_EARLY;
   // ... and their loaders skip the row groups a slice does not need, counting DMA instructions per
   // slice; small workgroups keep every slice the same number of instructions (cheaper bookkeeping:
   // measured 3 % on the 512^3 frame, where the loaders' issue slots are the consumers')
 #ifndef SLAB_SMALL_FIFO
 #define SLAB_SMALL_FIFO 0
 #endif
-  constexpr bool FIFO = EARLY || SLAB_SMALL_FIFO;
+  constexpr bool FIFO = BIG || SLAB_SMALL_FIFO;
   // Small workgroups: the loaders take WHOLE slices in turn (loader l streams slices l, l + NL, ...) instead of a share of
   // the row groups of every slice.  A slice costs a loader ~120 scalar instructions before its first DMA (ring check,
   // table entry, 64-bit source address, column masks); with 3 DMA instructions per loader and slice that overhead was the
@@ -262,7 +266,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 #ifndef SLAB_BIG_NLG
 #define SLAB_BIG_NLG 2
 #endif
-  constexpr int NLG = !SLAB_ALT ? 1 : (EARLY ? ((NL % SLAB_BIG_NLG) == 0 ? SLAB_BIG_NLG : 1) : NL);
+  constexpr int NLG = !SLAB_ALT ? 1 : (BIG ? ((NL % SLAB_BIG_NLG) == 0 ? SLAB_BIG_NLG : 1) : NL);
   constexpr int LPG = NL / NLG;
   constexpr int QSTEP = NLG;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -568,7 +572,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 #endif
       // (big workgroups only: on the small ones' deep ring a late word costs little, and the look costs
       //  the kernel scalar registers -- 97 spilled SGPRs against 39)
-      constexpr bool EAGER = SLAB_EAGER && EARLY;
+      constexpr bool EAGER = SLAB_EAGER && BIG;
       auto publish_landed = [&](int cur) {
         if (!EAGER || inflight == 0) return;
         const unsigned st = __builtin_amdgcn_s_getreg((31 << 11) | 7);
@@ -653,7 +657,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
               // (small workgroups issue every row group of the window whatever the slice needs of it -- the instruction
               //  count is the same either way -- so a group that lies inside the window goes the branch-free way even
               //  when its last rows are not needed; the host makes the window a whole number of groups where it can)
-              if (row0 + (unsigned)rpg <= (EARLY ? need_v : (unsigned)Q.wv)) {
+              if (row0 + (unsigned)rpg <= (BIG ? need_v : (unsigned)Q.wv)) {
                 if (per == 3) {
                   // a whole group in ONE statement: EXEC takes each chunk's column mask in turn, M0 steps
                   // through the chunks' LDS images -- three scalar instructions per chunk and no branch
