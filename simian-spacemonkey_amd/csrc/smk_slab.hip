@@ -920,14 +920,25 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   smk_lerp(smk_lerp(smk_lerp(E(0, 0, 0), E(1, 0, 0), fx), smk_lerp(E(0, 1, 0), E(1, 1, 0), fx), fy),                       \
            smk_lerp(smk_lerp(E(0, 0, 1), E(1, 0, 1), fx), smk_lerp(E(0, 1, 1), E(1, 1, 1), fx), fy), fz)
           float ch0, ch1, ch2 = 0.f, ch3 = 0.f;
+          // big workgroups, float voxels, separable table: the third channel is only looked at behind the (v, g) quad's
+          // occupancy bit -- one sample in fourteen on the 1024^3 frame -- and its corners are in registers anyway, so
+          // its interpolation (14 packed instructions) waits until then
+          const bool lazy_h = EARLY && DT == 1 && TF == 1 && Q.fast_tf;
+          auto tri_h_early = [&]() -> float {
+            if constexpr (EARLY && DT == 1) {
+#define E2(dx, dy, dz) rq[QI(dx, dy, dz)].z
+              return TRI(E2);
+#undef E2
+            } else {
+              return 0.f;
+            }
+          };
           if constexpr (EARLY && DT == 1) {
 #define E0(dx, dy, dz) rq[QI(dx, dy, dz)].x
 #define E1(dx, dy, dz) rq[QI(dx, dy, dz)].y
-#define E2(dx, dy, dz) rq[QI(dx, dy, dz)].z
             ch0 = TRI(E0);
             ch1 = TRI(E1);
-            if (TF == 2 || P.third_axis) ch2 = TRI(E2);
-#undef E2
+            if ((TF == 2 || P.third_axis) && !lazy_h) ch2 = tri_h_early();
 #undef E1
 #undef E0
           } else if constexpr (EARLY && DT == 0) {
@@ -1001,6 +1012,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
               tx4 = slab_tex2d_fetch(P.tf_vg, P.sv, s0, t0, fs, ft);
               col.w = slab_tex_chan(tx4, 3);
               if (Q.use_ah) {  // third-axis alpha (the same products as smk_classify)
+                if (lazy_h) ch2 = tri_h_early();
                 int h0, h1;
                 float fh;
                 smk_lin_clamp(__fmaf_rn(ch2, (float)P.sv, -0.5f), P.sv, h0, h1, fh);
