@@ -125,6 +125,11 @@ __device__ __forceinline__ void slab_read8_nb16(unsigned a, unsigned ap, unsigne
   a += 12; ap += 12; b += 12; bp += 12;
   SLAB_READ8("ds_read_b32", "16");
 }
+// the third float channel of the 8 corners (16-byte voxels), read on its own behind the (v, g) occupancy bit
+__device__ __forceinline__ void slab_read8_h16(unsigned a, unsigned ap, unsigned b, unsigned bp, uint32_t (&q)[8]) {
+  a += 8; ap += 8; b += 8; bp += 8;
+  SLAB_READ8("ds_read_b32", "16");
+}
 __device__ __forceinline__ void slab_read8_nb8(unsigned a, unsigned ap, unsigned b, unsigned bp, uint32_t (&q)[8]) {
   a += 4; ap += 4; b += 4; bp += 4;
   SLAB_READ8("ds_read_b32", "8");
@@ -923,10 +928,18 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           // big workgroups, float voxels, separable table: the third channel is only looked at behind the (v, g) quad's
           // occupancy bit -- one sample in fourteen on the 1024^3 frame -- and its corners are in registers anyway, so
           // its interpolation (14 packed instructions) waits until then
-          const bool lazy_h = EARLY && DT == 1 && TF == 1 && Q.fast_tf;
+          // (small workgroups: the ring slots are still held, so the third channel is READ only then, too: 8 x 8 bytes
+          //  per sample instead of 8 x 12)
+          const bool lazy_h = DT == 1 && TF == 1 && Q.fast_tf;
           auto tri_h_early = [&]() -> float {
             if constexpr (EARLY && DT == 1) {
 #define E2(dx, dy, dz) rq[QI(dx, dy, dz)].z
+              return TRI(E2);
+#undef E2
+            } else if constexpr (DT == 1) {
+              uint32_t hq[8];
+              slab_read8_h16(a0, a0 + pitch_b, b0, b0 + pitch_b, hq);
+#define E2(dx, dy, dz) __uint_as_float(hq[QI(dx, dy, dz)])
               return TRI(E2);
 #undef E2
             } else {
@@ -957,7 +970,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 #undef E1
 #undef E0
           } else if constexpr (DT == 1) {
-            if (TF == 2 || P.third_axis) {
+            if ((TF == 2 || P.third_axis) && !lazy_h) {
               v3f q[8];
               slab_read8(a0, a0 + pitch_b, b0, b0 + pitch_b, q);
 #define E0(dx, dy, dz) q[QI(dx, dy, dz)].x
