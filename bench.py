@@ -524,7 +524,9 @@ def main():
         # gather, csrc/smk_exchange.hip) wherever every rank has its own GPU; the rehearsal on one GPU
         # (RCCL does not run two ranks on one device) goes through torch.distributed/gloo instead
         exchange_mode, xchg = "torch.distributed all_to_all_single + gather (gloo, rehearsal)", None
-        if not rehearse:
+        if not rehearse and os.environ.get("SMK_BENCH_EXCHANGE") == "torch":   # (operator's switch: skip the C exchange)
+            exchange_mode = "torch.distributed all_to_all_single + gather over RCCL (SMK_BENCH_EXCHANGE=torch)"
+        elif not rehearse:
             ok = 1
             try:
                 uid = [pkg.exchange_unique_id() if rank == 0 else None]
