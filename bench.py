@@ -344,6 +344,16 @@ def extra_legs(r, frame, work, steps):
     torch.cuda.empty_cache()
     configure(r, "cfg4", n1, 1024, 512)
     run("north_star_on_round1_input", 1024, 512, "the north-star frame on round 1's synthetic volume (smk_synth_volume_device kind 0)")
+    # the same 1024^3 frame from a u8 VGH volume (what the reference's loader produces: MetaVolume quantises to bytes):
+    # 8-byte packed voxels carry 6 bytes of data + normal
+    vghf, nrm = make_volume(r, n1)
+    v8 = (vghf * 255.0).to(torch.uint8)
+    del vghf
+    r.upload_volume_device(v8.data_ptr(), (n1, n1, n1), 3, 0, nrm.data_ptr())
+    del v8, nrm
+    torch.cuda.empty_cache()
+    configure(r, "cfg4", n1, 1024, 512)
+    run("north_star_u8", 1024, 512, "the north-star frame from a 1024^3 u8 VGH volume (6 algorithmic bytes per voxel in 8-byte packed voxels)")
     # BASELINE config 5 on one GPU: two 512^3 fields merged on the GPU (mergeMV + addG), dense 3-D table,
     # noise-perturbed fetch (createNoiseTex's texture, gluvvui's default weights (.2, 0) would displace by 51
     # voxels: SURVEY 8d's (.2, .1) scaled to the volume, see DESIGN), 1024^2 x 1024
