@@ -932,9 +932,19 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           // its interpolation (14 packed instructions) waits until then
           // (small workgroups: the ring slots are still held, so the third channel is READ only then, too: 8 x 8 bytes
           //  per sample instead of 8 x 12)
-          const bool lazy_h = DT == 1 && TF == 1 && Q.fast_tf;
+          // (byte voxels: all four channels come in one word per corner, the interpolation alone is deferred)
+          const bool lazy_h = TF == 1 && Q.fast_tf;
+          uint32_t q8[DT == 0 && !EARLY ? 8 : 1];  // small workgroups, byte voxels: the corners' data words
           auto tri_h_early = [&]() -> float {
-            if constexpr (EARLY && DT == 1) {
+            if constexpr (EARLY && DT == 0) {
+#define E2(dx, dy, dz) smk_ub(rq[QI(dx, dy, dz)].x, 2)
+              return TRI(E2) * SMK_INV255;
+#undef E2
+            } else if constexpr (DT == 0) {
+#define E2(dx, dy, dz) smk_ub(q8[QI(dx, dy, dz)], 2)
+              return TRI(E2) * SMK_INV255;
+#undef E2
+            } else if constexpr (EARLY && DT == 1) {
 #define E2(dx, dy, dz) rq[QI(dx, dy, dz)].z
               return TRI(E2);
 #undef E2
@@ -963,7 +973,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 #define E3(dx, dy, dz) smk_ub(rq[QI(dx, dy, dz)].x, 3)
             ch0 = TRI(E0) * SMK_INV255;
             ch1 = TRI(E1) * SMK_INV255;
-            if (TF == 2 || P.third_axis) {
+            if ((TF == 2 || P.third_axis) && !lazy_h) {
               ch2 = TRI(E2) * SMK_INV255;
               if (P.nelts == 4) ch3 = TRI(E3) * SMK_INV255;
             }
@@ -991,15 +1001,15 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 #undef E0
             }
           } else {
-            uint32_t q[8];
-            slab_read8_u8(a0, a0 + pitch_b, b0, b0 + pitch_b, q);
+            uint32_t (&q)[DT == 0 && !EARLY ? 8 : 1] = q8;
+            if constexpr (DT == 0 && !EARLY) slab_read8_u8(a0, a0 + pitch_b, b0, b0 + pitch_b, q8);
 #define E0(dx, dy, dz) smk_ub(q[QI(dx, dy, dz)], 0)
 #define E1(dx, dy, dz) smk_ub(q[QI(dx, dy, dz)], 1)
 #define E2(dx, dy, dz) smk_ub(q[QI(dx, dy, dz)], 2)
 #define E3(dx, dy, dz) smk_ub(q[QI(dx, dy, dz)], 3)
             ch0 = TRI(E0) * SMK_INV255;
             ch1 = TRI(E1) * SMK_INV255;
-            if (TF == 2 || P.third_axis) {
+            if ((TF == 2 || P.third_axis) && !lazy_h) {
               ch2 = TRI(E2) * SMK_INV255;
               if (P.nelts == 4) ch3 = TRI(E3) * SMK_INV255;
             }
