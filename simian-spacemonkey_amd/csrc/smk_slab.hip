@@ -933,7 +933,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           // (small workgroups: the ring slots are still held, so the third channel is READ only then, too: 8 x 8 bytes
           //  per sample instead of 8 x 12)
           // (byte voxels: all four channels come in one word per corner, the interpolation alone is deferred)
-          const bool lazy_h = TF == 1 && Q.fast_tf;
+          const bool lazy_h = (TF == 1 && Q.fast_tf) || (TF == 2 && Q.use_occ);
           uint32_t q8[DT == 0 && !EARLY ? 8 : 1];  // small workgroups, byte voxels: the corners' data words
           auto tri_h_early = [&]() -> float {
             if constexpr (EARLY && DT == 0) {
@@ -1055,7 +1055,10 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             smk_lin_clamp(__fmaf_rn(ch1, (float)P.s3g, -0.5f), P.s3g, t0, t1, ft);
             col.w = 0.0f;
             hit = false;
-            if ((occ[__mul24(t0, P.occ_roww) + (s0 >> 5)] >> (s0 & 31)) & 1u) hit = smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col);
+            if ((occ[__mul24(t0, P.occ_roww) + (s0 >> 5)] >> (s0 & 31)) & 1u) {
+              ch2 = tri_h_early();  // (the third coordinate of the lookup: only now)
+              hit = smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col);
+            }
           } else {
             hit = smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col);
           }
