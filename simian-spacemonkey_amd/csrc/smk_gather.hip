@@ -141,6 +141,16 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
       ch1 = SMK_TRI(c1);
       if (DT == 0) ch1 *= sc;
     }
+    float4 col;
+    if (TF == 2 && P.tf_occ) {
+      // dense 3-D table: a clear occupancy bit of the (v, g) base texel (folded over the sheets, smk_set_tf3d) means the
+      // eight-texel lookup returns alpha == 0 exactly -- checked before the third channel is even interpolated
+      int s0, s1, t0, t1;
+      float fs, ft;
+      smk_lin_clamp(__fmaf_rn(ch0, (float)P.s3v, -0.5f), P.s3v, s0, s1, fs);
+      smk_lin_clamp(__fmaf_rn(ch1, (float)P.s3g, -0.5f), P.s3g, t0, t1, ft);
+      if (!((P.tf_occ[t0 * P.occ_roww + (s0 >> 5)] >> (s0 & 31)) & 1u)) continue;
+    }
     if (TF == 2 || (TF == 1 && P.third_axis)) {
       ch2 = SMK_TRI(c2);
       if (DT == 0) ch2 *= sc;
@@ -150,16 +160,6 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
       }
     }
 
-    float4 col;
-    if (TF == 2 && P.tf_occ) {
-      // dense 3-D table: a clear occupancy bit of the (v, g) base texel (folded over the sheets, smk_set_tf3d) means the
-      // eight-texel lookup returns alpha == 0 exactly
-      int s0, s1, t0, t1;
-      float fs, ft;
-      smk_lin_clamp(__fmaf_rn(ch0, (float)P.s3v, -0.5f), P.s3v, s0, s1, fs);
-      smk_lin_clamp(__fmaf_rn(ch1, (float)P.s3g, -0.5f), P.s3g, t0, t1, ft);
-      if (!((P.tf_occ[t0 * P.occ_roww + (s0 >> 5)] >> (s0 & 31)) & 1u)) continue;
-    }
     if (!smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col)) continue;
 
     float4 src;
