@@ -1130,6 +1130,9 @@ static int build_params(smk_ctx *c, RenderParams &P, hipStream_t s) {
   P.blend = c->blend;
   P.noise = c->d_noise;
   P.nn = c->nn;
+  P.nn_log2 = -1;
+  for (int l = 0; l < 12; ++l)
+    if (c->nn == (1 << l)) P.nn_log2 = l;
   P.pw[0] = c->pw[0];
   P.pw[1] = c->pw[1];
   P.ps[0] = c->ps[0];

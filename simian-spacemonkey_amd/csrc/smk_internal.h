@@ -55,6 +55,7 @@ struct RenderParams {
   // ---- perturbation
   const uint32_t *noise;  // [nn][nn][nn] RGBA8
   int nn, pert_on;
+  int nn_log2;  // log2(nn) when the noise texture's edge is a power of two, else -1
   float pw[2], ps[2];
   // ---- output
   float4 *out;
