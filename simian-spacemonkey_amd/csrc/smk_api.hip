@@ -66,6 +66,8 @@ static void free_volume(smk_ctx *c) {
   if (c->d_vox) (void)hipFree(c->d_vox);
   if (c->d_nrm) (void)hipFree(c->d_nrm);
   if (c->d_vox_x) (void)hipFree(c->d_vox_x);
+  if (c->d_brick_mm) (void)hipFree(c->d_brick_mm);
+  c->d_brick_mm = nullptr;
   c->d_vox_x = nullptr;
   c->d_vox = nullptr;
   c->d_nrm = nullptr;
@@ -80,10 +82,12 @@ extern "C" void smk_destroy(smk_ctx *c) {
   for (smk_ctx::TfVersion &T : c->tfv) {
     if (T.d) (void)hipFree(T.d);
     if (T.h) (void)hipHostFree(T.h);
+    if (T.bricks) (void)hipFree(T.bricks);
+    if (T.sat) (void)hipFree(T.sat);
     if (T.copied) (void)hipEventDestroy(T.copied);
     if (T.used) (void)hipEventDestroy(T.used);
   }
-  void *ptrs[] = {c->d_tlut, c->d_tf_h, c->d_tf3d, c->d_tf3d_occ, c->d_noise, c->d_out, c->d_depth, c->d_light[0], c->d_light[1]};
+  void *ptrs[] = {c->d_bricks3, c->d_sat3, c->d_tlut, c->d_tf_h, c->d_tf3d, c->d_tf3d_occ, c->d_noise, c->d_out, c->d_depth, c->d_light[0], c->d_light[1]};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->slab.h_status) (void)hipHostFree(c->slab.h_status);
@@ -275,6 +279,12 @@ static int upload_impl(smk_ctx *c, const smk_volume_desc *b, int nb, int nelts, 
   }
   if (d_stage) (void)hipFree(d_stage);
   if (d_gstage) (void)hipFree(d_gstage);
+  // value ranges of the 8x8x8-cell bricks (smk_bricks.hip): what the brick flags of every later table are made from
+  for (int a = 0; a < 3; ++a) c->nbr[a] = (c->D[a] - 1) / (1 << SMK_BRICK_LOG2) + 1;
+  HIPCHK(c, hipMalloc((void **)&c->d_brick_mm, (size_t)c->nbr[0] * c->nbr[1] * c->nbr[2] * sizeof(float4)));
+  HIPCHK(c, smk_bricks_minmax(c->d_vox, dtype == SMK_U8 ? 0 : 1, c->D, c->nbr, c->d_brick_mm, 0));
+  HIPCHK(c, hipDeviceSynchronize());
+  c->bricks3_dirty = true;
   c->have_volume = true;
   c->tune_choice.clear();  // a new volume: the kernels' relative speed is measured afresh
   c->tune_sig = 0;
@@ -405,6 +415,7 @@ extern "C" int smk_set_tf3d(smk_ctx *c, const unsigned char *ptex, int sv, int s
   c->s3g = sg;
   c->s3h = sh;
   c->tf_mode = 2;
+  c->bricks3_dirty = true;
   return 0;
 }
 
@@ -852,6 +863,25 @@ static int refresh_tf2d(smk_ctx *c, const smk_raycoef &rc, hipStream_t s) {
   c->tf_cur = v;
   c->d_tf_vg = reinterpret_cast<uint32_t *>(T.d);
   c->d_tf_occ = reinterpret_cast<uint32_t *>(T.d + n * 4);
+  // this version's brick flags (smk_bricks.hip), behind the copy on the same stream: two small launches per refresh
+  if (c->opt_bricks && c->d_brick_mm) {
+    const size_t nbricks = (size_t)c->nbr[0] * c->nbr[1] * c->nbr[2], sat_words = (size_t)(sv + 1) * (sg + 1);
+    if (T.bricks_cap < nbricks) {  // (a new volume size: rare; hipFree waits for the frames in flight)
+      if (T.bricks) (void)hipFree(T.bricks);
+      T.bricks = nullptr;
+      T.bricks_cap = 0;
+      HIPCHK(c, hipMalloc((void **)&T.bricks, nbricks));
+      T.bricks_cap = nbricks;
+    }
+    if (T.sat_cap < sat_words) {
+      if (T.sat) (void)hipFree(T.sat);
+      T.sat = nullptr;
+      T.sat_cap = 0;
+      HIPCHK(c, hipMalloc((void **)&T.sat, sat_words * 4));
+      T.sat_cap = sat_words;
+    }
+    HIPCHK(c, smk_bricks_flags(c->d_brick_mm, c->nbr, c->d_tf_occ, roww, sv, sg, T.sat, T.bricks, s));
+  }
   c->tf_occ_roww = roww;
   c->tf_rate_applied = sr;
   c->tf_dirty = false;
@@ -906,6 +936,11 @@ extern "C" int smk_set_option(smk_ctx *c, const char *key, int value) {
   else if (!strcmp(key, "slab_sched")) c->opt_slab_sched = value < 0 ? 0 : (value > 15 ? 15 : value);
   else if (!strcmp(key, "slab_ns")) c->opt_slab_ns = value < 0 ? 0 : (value > 63 ? 63 : value);
   else if (!strcmp(key, "tile")) c->opt_tile = value;
+  else if (!strcmp(key, "bricks")) {  // 0: the slice-ring kernel streams and samples every slice (smk_bricks.hip off)
+    c->opt_bricks = value ? 1 : 0;
+    c->tf_dirty = true;
+    c->bricks3_dirty = true;
+  }
   else if (!strcmp(key, "wave_w")) {
     if (!(value == 1 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || value == 64)) FAIL(c, "smk_set_option: wave_w must be a power of two <= 64");
     c->opt_wave_w = value;
@@ -1123,6 +1158,26 @@ static int build_params(smk_ctx *c, RenderParams &P, hipStream_t s) {
   P.s3v = c->s3v;
   P.s3g = c->s3g;
   P.s3h = c->s3h;
+  // brick flags (smk_bricks.hip): the 2-D table's come with its version; the dense 3-D table's are made here when stale
+  P.bricks = nullptr;
+  for (int a = 0; a < 3; ++a) P.nbr[a] = c->nbr[a];
+  if (c->opt_bricks && c->d_brick_mm) {
+    if (c->tf_mode == 1 && c->tf_cur >= 0) P.bricks = c->tfv[c->tf_cur].bricks;
+    if (c->tf_mode == 2 && c->d_tf3d_occ) {
+      if (c->bricks3_dirty || !c->d_bricks3) {
+        HIPCHK(c, hipDeviceSynchronize());  // (a new table or volume: rare; frames in flight may still read the old flags)
+        if (c->d_bricks3) (void)hipFree(c->d_bricks3);
+        if (c->d_sat3) (void)hipFree(c->d_sat3);
+        c->d_bricks3 = nullptr;
+        c->d_sat3 = nullptr;
+        HIPCHK(c, hipMalloc((void **)&c->d_bricks3, (size_t)c->nbr[0] * c->nbr[1] * c->nbr[2]));
+        HIPCHK(c, hipMalloc((void **)&c->d_sat3, (size_t)(c->s3v + 1) * (c->s3g + 1) * 4));
+        HIPCHK(c, smk_bricks_flags(c->d_brick_mm, c->nbr, c->d_tf3d_occ, c->tf3d_occ_roww, c->s3v, c->s3g, c->d_sat3, c->d_bricks3, s));
+        c->bricks3_dirty = false;
+      }
+      P.bricks = c->d_bricks3;
+    }
+  }
   P.W = c->W;
   P.H = c->H;
   P.znear = c->clip[0];

@@ -12,6 +12,7 @@
 
 #define SMK_MAX_RANKS 8
 #define SMK_TIMING_RING 64
+#define SMK_BRICK_LOG2 3   // bricks of 8x8x8 cells (smk_bricks.hip)
 #define SMK_STATUS_RING 8  // frames whose slice-ring status stays readable (smk_frame_failed)
 
 // Everything a render kernel needs, passed by value as the kernarg (wave-uniform => SGPRs).
@@ -42,6 +43,10 @@ struct RenderParams {
   int sv, sg, third_axis;
   const uint32_t *tf3d;  // [s3h][s3g][s3v]
   int s3v, s3g, s3h;
+  // ---- brick flags (smk_bricks.hip): [nbr[2]][nbr[1]][nbr[0]] bytes over the stored box, 0 = no sample whose cell lies in
+  // the brick can be visible under the current table; null = not available (1-D colour table, option "bricks" 0)
+  const unsigned char *bricks;
+  int nbr[3];
   // ---- camera / sample placement
   smk_raycoef rc;
   int W, H;
@@ -123,6 +128,11 @@ struct smk_ctx {
   double cplane_eye[4] = {0, 0, 0, 0};
   void *d_vox = nullptr;
   void *d_vox_x = nullptr;  // x-major copy [x][z][y] for views whose principal axis is x (lazy)
+  float4 *d_brick_mm = nullptr;  // per brick of the stored box: range of the first two channels (smk_bricks.hip)
+  int nbr[3] = {0, 0, 0};
+  unsigned char *d_bricks3 = nullptr;  // brick flags under the dense 3-D table (the 2-D table's live in its versions)
+  uint32_t *d_sat3 = nullptr;
+  bool bricks3_dirty = true;
   std::string slab_why;     // why the last frame fell back to the gather kernel ("" if it did not)
   uint32_t *d_nrm = nullptr;
   bool have_normals = false;
@@ -145,6 +155,9 @@ struct smk_ctx {
   // stalling the frames in flight when the correction rate moves with the camera (smk_api.hip refresh_tf2d)
   struct TfVersion {
     unsigned char *d = nullptr, *h = nullptr;  // device copy; pinned staging
+    unsigned char *bricks = nullptr;            // this version's brick flags (smk_bricks.hip) + the summed-area table they
+    uint32_t *sat = nullptr;                    // were made from; sized for the volume / the table when first needed
+    size_t bricks_cap = 0, sat_cap = 0;
     size_t cap = 0;
     hipEvent_t copied = nullptr, used = nullptr;
     bool used_valid = false;
@@ -192,6 +205,7 @@ struct smk_ctx {
   int opt_kernel = 0, opt_slab_T = 0, opt_tf_raw = 0, opt_tile = 0;
   int opt_slab_fly = 0;  // slices a loader keeps in flight (0 = default)
   int opt_slab_ns = 0;   // cap on the ring's slots (0 = as many as fit)
+  int opt_bricks = 1;      // brick flags on (0: every slice is streamed and sampled, as before round 2's last step)
   int opt_slab_sched = 0;  // order of an XCD's tiles: 0 longest first, 1.. coarse weight classes + spatial blocks
   int opt_inject_status = 0;  // (test hook) the next slice-ring frame reports this status word
   int opt_wave_w = 8, opt_blk_w = 2, opt_lockstep = 1;
@@ -211,6 +225,11 @@ struct smk_ctx {
   float last_ms = 0;
   double last_alg_bytes = 0;
 };
+
+// brick flags (smk_bricks.hip)
+hipError_t smk_bricks_minmax(const void *vox, int dtype, const int D[3], const int nb[3], float4 *mm, hipStream_t s);
+hipError_t smk_bricks_flags(const float4 *mm, const int nb[3], const uint32_t *occ, int roww, int sv, int sg, uint32_t *sat,
+                            unsigned char *flags, hipStream_t s);
 
 // launchers (one translation unit per kernel family)
 hipError_t smk_launch_gather(const RenderParams &P, int dtype, int tf_mode, int shade_kind,

@@ -64,6 +64,8 @@ struct SlabParams {
   int use_ah;                  // third-axis alpha served from a 1-D LDS table (<= 3 channels)
   int use_occ;                 // (V,G) occupancy bitmap copied to LDS
   int fast_tf;                 // alpha-first classification with 8-byte texel loads (no third axis, or use_ah)
+  const unsigned char *bricks;  // brick flags of the stored box (smk_bricks.hip) or null: see "EMPTY LAYERS" in the kernel
+  int bsu, bsv, bss;           // their strides along U, V, S (in bricks)
   const int *order;            // tile of each block (work-balanced schedule, -1 = none), see smk_launch_slab
   unsigned *tile_ticks;        // [3][ntiles]: duration of each tile's workgroup in 100 MHz ticks (next frame's weights) |
                                // slices its loaders streamed | slices of its range (the loaders stop once every ray of
@@ -393,6 +395,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   if (tid == 0) {
     ctl[0] = 0x7fffffff;
     ctl[1] = -0x7fffffff;
+    ctl[2] = 0;  // slices the loaders did not have to stream (EMPTY LAYERS)
     ctl[3] = 0;  // error flag (bounded spins, window bound)
     for (int l = 0; l < 4; ++l) ctl[4 + l] = l < NL ? l % NLG : 0x7fffffff;  // (a loader's first slice) absent loaders never hold anyone back
   }
@@ -488,6 +491,60 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       wtab[e] = ent;
     }
   }
+  // ---- EMPTY LAYERS.  The cells between slices b and b + 1 ("layer b") that this tile's rays can cross lie in the
+  // overlap of the two slices' windows.  When every brick that overlap touches is flagged empty (smk_bricks.hip: no
+  // sample in it can be visible under the current table), nobody in the tile samples layer b -- bit 0 of the entry --
+  // and a slice whose two neighbouring layers are both empty is not streamed at all -- bit 1.  (The entries' base
+  // addresses are multiples of 8.)  A sample that IS taken therefore finds both its slices loaded: its layer's bit 0 is
+  // clear, which keeps bit 1 of both slices clear.
+  if (Q.bricks != nullptr && npos > 0) {
+    constexpr int BL = SMK_BRICK_LOG2;
+    __syncthreads();
+    auto extent = [&](int e, int &ulo, int &uhi, int &vlo, int &vhi) {
+      const unsigned pk = wtab[e].pack;
+      ulo = (int)(pk & 0x7ffu);
+      vlo = (int)((pk >> 11) & 0x7ffu);
+      uhi = ulo + (int)(((pk >> 22) & 0x3fu) + 1u) * UPV - 1;
+      vhi = vlo + (Q.wv - (int)(pk >> 28) * ((Q.wv + 15) / 16)) - 1;
+    };
+    for (int q = tid; q <= npos; q += NTH) {
+      const int sl = dir > 0 ? smin + q : smax + 1 - q;
+      const int e = sl - Q.Os;
+      if (e < 0 || e >= Q.Ds) continue;
+      bool none = true;
+      if (sl <= smax) {
+        int ulo, uhi, vlo, vhi;
+        extent(e, ulo, uhi, vlo, vhi);
+        if (e + 1 < Q.Ds) {  // (slice sl + 1 <= smax + 1 is in the tile's range: its entry is filled)
+          int u2, u3, v2, v3;
+          extent(e + 1, u2, u3, v2, v3);
+          ulo = max(ulo, u2);
+          uhi = min(uhi, u3);
+          vlo = max(vlo, v2);
+          vhi = min(vhi, v3);
+        }
+        // lower corners of the cells: one less than the voxels at the top end
+        uhi = min(uhi, Q.Du - 1) - 1;
+        vhi = min(vhi, Q.Dv - 1) - 1;
+        if (uhi >= ulo && vhi >= vlo) {
+          const unsigned char *row = Q.bricks + (size_t)(e >> BL) * Q.bss;
+          for (int bv = vlo >> BL; bv <= (vhi >> BL); ++bv)
+            for (int bu = ulo >> BL; bu <= (uhi >> BL); ++bu)
+              if (row[(size_t)bv * Q.bsv + (size_t)bu * Q.bsu]) none = false;
+        }
+      }
+      if (none) wtab[e].base |= 1;
+    }
+    __syncthreads();
+    for (int q = tid; q <= npos; q += NTH) {
+      const int sl = dir > 0 ? smin + q : smax + 1 - q;
+      const int e = sl - Q.Os;
+      if (e < 0 || e >= Q.Ds) continue;
+      const bool mine = sl <= smax && !(wtab[e].base & 1);
+      const bool below = sl - 1 >= smin && e - 1 >= 0 && !(wtab[e - 1].base & 1);
+      if (!mine && !below) wtab[e].base |= 2;
+    }
+  }
   // every consumer wave announces the first position it needs before anyone moves on
   const int psgn = dir > 0 ? 1 : -1, poff = dir > 0 ? -smin : smax;  // position of base slice b = psgn*b + poff
   int pb = SLAB_DONE;  // position of this ray's next sample
@@ -567,6 +624,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       //  column masks cached across slices in a VGPR bit set -- 1024^3 3.54 -> 3.74 ms: the scalar
       //  per-slice arithmetic below is cheaper than it looks, the extra VALU is not.)
       int ent_uv = 0, tab_base = -64;
+      int ent_skip = 0;  // ... and whether anybody needs the slice at all (EMPTY LAYERS, bit 1 of the entry's base)
+      int n_skipped = 0;
       // EAGER PUBLICATION.  A slice used to be published when its loader, done issuing the NEXT one, waited
       // for it -- up to a slice's issue time (~0.5 us) after it had landed, on a ring that is a few slices
       // deep.  The wave's outstanding vector-memory count can be READ (s_getreg HW_REG_IB_STS: VM_CNT in
@@ -617,12 +676,25 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             const int ql = tab_base + lane;
             const int e = (dir > 0 ? smin + ql : smax + 1 - ql) - Q.Os;
             ent_uv = -1;
-            if (ql <= npos && e >= 0 && e < Q.Ds) ent_uv = (int)raw_lds_b64(&wtab[e]).y;  // (.pack; never -1: u0 < 2^11)
+            ent_skip = 0;
+            if (ql <= npos && e >= 0 && e < Q.Ds) {
+              const auto ent = raw_lds_b64(&wtab[e]);
+              ent_uv = (int)ent.y;  // (.pack; never -1: u0 < 2^11)
+              ent_skip = ((int)ent.x >> 1) & 1;
+            }
           }
           const int uv = __builtin_amdgcn_readlane(ent_uv, q & 63);
+          // a slice nobody samples is not streamed.  Small windows count on every slice being the same number of DMA
+          // instructions (the in-order vmcnt): there the slice may issue nothing only while none is in flight before it
+          // -- else it goes the uniform way with `mych` one-unit reads.
+          bool skip = Q.bricks != nullptr && __builtin_amdgcn_readlane(ent_skip, q & 63) != 0;
+          if (!FIFO && inflight > 0) skip = false;
+          if (skip && gl == 0) ++n_skipped;
           int issued = 0;  // DMA wave-instructions of this slice (this loader's share)
           const unsigned dst0 = ring_addr + (unsigned)(slot_q * Q.slot_bytes + gl * per * 1024);
-          if (uv != -1) {
+          if (skip) {
+            // nothing
+          } else if (uv != -1) {
             // (small windows: the whole shape -- the saving would not pay for the partial-group path)
 #ifndef SLAB_LIGHT_FULLROWS
 #define SLAB_LIGHT_FULLROWS 0
@@ -763,6 +835,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       }
 #undef SLAB_DMA
       wait_vmcnt(0);
+      if (n_skipped && lane == 0) atomicAdd(&ctl[2], n_skipped);
       if (tracing && lane == 0 && lid == 0) {
         unsigned *t = Q.trace + 8 * (size_t)blockIdx.x;
         t[4] = (unsigned)(t_issue >> 6);
@@ -874,12 +947,19 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
         typename std::conditional<DT == 0, v2u, v4f>::type rq[EARLY ? 8 : 1];
         float early_nsc = 0.f;
         int early_ni = 0;
-        const bool work = act && !stream_only;
+        bool work = act && !stream_only;
+        int base_a = 0, base_b = 0;
         if (work) {
           // the two slices' slot images (one 8-byte table entry each, adjacent): issued first,
           // the position arithmetic below covers the LDS round trip
           const int *te = reinterpret_cast<const int *>(smem + (wtab_addr - ring_addr)) + 2 * (__mul24(psgn, pb) + eoff);  // (24-bit multiply: full rate; |pb| < 4096 on a lane that works)
-          const int base_a = te[0], base_b = te[2];
+          base_a = te[0];
+          base_b = te[2] & ~1;  // (bit 0: the NEXT layer's flag)
+        }
+        // EMPTY LAYERS: nothing in this sample's layer can be visible for any ray of the tile -- the sample is exactly
+        // transparent, and its slices may not even have been streamed
+        if (Q.bricks != nullptr) work = work && !(base_a & 1);
+        if (work) {
           const float mf = (float)m;
           // (no membership test: [m, m1] is exactly the inside interval, see the set-up)
           // (the principal axis' clamped coordinate and base index were computed when this sample's position in
@@ -1162,7 +1242,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   if (tid == 0 && Q.tile_ticks) {
     Q.tile_ticks[tile] = max((unsigned)__builtin_amdgcn_s_memrealtime() - trace_t0, 1u);
     // (ctl[4..7] = the loaders' landed words, final after the barrier above; their minimum = slices completely streamed)
-    Q.tile_ticks[Q.ntiles + tile] = npos > 0 ? (unsigned)min(max(min(min(ctl[4], ctl[5]), min(ctl[6], ctl[7])), 0), npos + 1) : 0u;
+    // (less the slices that were not streamed because nobody samples them: EMPTY LAYERS)
+    Q.tile_ticks[Q.ntiles + tile] = npos > 0 ? (unsigned)max(min(max(min(min(ctl[4], ctl[5]), min(ctl[6], ctl[7])), 0), npos + 1) - ctl[2], 0) : 0u;
     Q.tile_ticks[2 * Q.ntiles + tile] = npos > 0 ? (unsigned)(npos + 1) : 0u;
   }
   if (tracing && tid == 0) {
@@ -1633,6 +1714,13 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     // (measured: 5.99 -> 5.61 ms on 1024^3, where the texel gathers share the texture path with a
     //  heavy stream; no gain at 512^3, where the 8 KB are worth more as ring slots)
     Q.use_occ = ((Q.fast_tf || tf_mode == 2) && Q.mask_need && P.tf_occ && occ_bytes > 0 && occ_bytes <= 8192) ? 1 : 0;
+    {  // brick flags (EMPTY LAYERS in the kernel): model-axis strides -> the kernel's (U, V, S)
+      Q.bricks = (tf_mode == 1 || tf_mode == 2) ? P.bricks : nullptr;
+      const int bst[3] = {1, P.nbr[0], P.nbr[0] * P.nbr[1]};
+      Q.bsu = bst[Q.au];
+      Q.bsv = bst[Q.av];
+      Q.bss = bst[Q.as];
+    }
     const size_t fixed = (size_t)Q.Ds * sizeof(SlabEnt) + (8 + 32) * 4 + 64 + (Q.use_ah ? (size_t)P.sv * 4 : 0) + (Q.use_occ ? occ_bytes : 0);
     // ring: as many slots as fit two workgroups per CU (small tiles) or one (big tiles)
     size_t budget = (nw + nl) > SLAB_BIG_WAVES ? 158 * 1024 : 78 * 1024;

@@ -1,0 +1,111 @@
+"""Brick flags (smk_bricks.hip): layers of cells in which no sample can be visible under the current table are
+neither streamed nor sampled by the slice-ring kernel.  The skipped samples are exactly transparent, so the
+frame must not change by a single bit -- against the same kernel with the flags off (option "bricks" 0),
+against the gather kernel, and (1e-4) against the CPU checker, which knows nothing of bricks."""
+import numpy as np
+import pytest
+
+from _scenes import POSES, make_scene, push_scene
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def R(gpu_renderer_factory):
+    r = gpu_renderer_factory()
+    yield r
+    r.set_option("bricks", 1)
+    r.close()
+
+
+def _three(R, sc, grid=(1, 1, 1)):
+    """frames of: gather kernel, slice ring without flags, slice ring with flags (+ streamed fractions)"""
+    R.set_option("bricks", 1)
+    push_scene(R, sc, grid)
+    R.set_option("kernel", 1)
+    g = R.render()
+    R.set_option("kernel", 2)
+    R.set_option("bricks", 0)
+    s0 = R.render()
+    assert R.last_frame_info()[0] == 2
+    f0 = R.stat("slab_streamed_fraction")
+    R.set_option("bricks", 1)
+    s1 = R.render()
+    assert R.last_frame_info()[0] == 2
+    f1 = R.stat("slab_streamed_fraction")
+    R.set_option("kernel", 0)
+    assert R.stat("slab_failures") == 0
+    return g, s0, s1, f0, f1
+
+
+@pytest.mark.parametrize("pose", sorted(POSES) + ["rot"])
+@pytest.mark.parametrize("f32", [False, True])
+def test_sparse_table_every_axis(R, pose, f32):
+    """the LevWidget table leaves most of a 96^3 volume transparent: slices are skipped, the frame is not touched"""
+    sc = make_scene("cfg3", n=96, size=160, steps=200, pose=pose, f32=f32, shade=1)
+    g, s0, s1, f0, f1 = _three(R, sc)
+    assert g[..., 3].max() > 0.05
+    assert np.array_equal(s0, g) and np.array_equal(s1, g)
+    assert f1 <= f0
+
+
+def test_flags_skip_something_and_the_checker_agrees(R):
+    sc = make_scene("cfg3", n=96, size=128, steps=160, pose="rot", f32=True, shade=1)
+    ref = sc.render()
+    g, s0, s1, f0, f1 = _three(R, sc)
+    assert np.array_equal(s1, g)
+    assert np.abs(s1 - ref).max() <= TOL
+    assert f1 < 0.95 * f0, "no slice was skipped (%g vs %g)" % (f1, f0)
+
+
+def test_flags_follow_the_table(R):
+    """a new table (and a new correction rate) brings new flags: first a table that hides everything but a band,
+    then an opaque one, then the first again -- each frame equal to the gather kernel's"""
+    sc = make_scene("cfg3", n=64, size=96, steps=128, pose="diag", f32=True, shade=1)
+    R.set_option("bricks", 1)
+    push_scene(R, sc)
+    band = np.zeros((256, 256, 4), np.uint8)
+    band[:, 100:120] = (200, 120, 40, 90)
+    opaque = np.full((256, 256, 4), 255, np.uint8)
+    for tf, steps in ((band, 128), (opaque, 128), (band, 96), (sc.tf_vg, 77)):
+        R.set_tf2d(tf, None)
+        R.set_sampling(0.0, steps, 1.0, 1)
+        R.set_option("kernel", 1)
+        g = R.render()
+        R.set_option("kernel", 2)
+        s = R.render()
+        assert R.last_frame_info()[0] == 2
+        assert np.array_equal(s, g)
+    R.set_option("kernel", 0)
+
+
+@pytest.mark.parametrize("kind,f32", [("tf3d_panes", True), ("tf3d_panes", False), ("cfg4", True), ("cfg2", False)])
+def test_other_tables(R, kind, f32):
+    """dense 3-D table (flags from its occupancy folded over the sheets), (v,g) x third axis, the default ramp"""
+    sc = make_scene(kind, n=64, size=96, steps=128, pose="side", f32=f32, shade=1)
+    ref = sc.render()
+    g, s0, s1, f0, f1 = _three(R, sc)
+    assert np.array_equal(s0, g) and np.array_equal(s1, g)
+    assert np.abs(s1 - ref).max() <= TOL
+
+
+@pytest.mark.parametrize("rank", [0, 3, 5])
+def test_shard_boxes(gpu_renderer_factory, rank):
+    """a shard stores its region + halo at an offset: the flags are indexed in stored-box coordinates"""
+    sc = make_scene("cfg3", n=64, size=96, steps=128, pose="rot", f32=True, shade=1)
+    r = gpu_renderer_factory()
+    try:
+        r.set_shard(rank, 8)
+        g, s0, s1, f0, f1 = _three(r, sc)
+        assert np.array_equal(s1, g) and np.array_equal(s0, g)
+    finally:
+        r.close()
+
+
+def test_ragged_and_thin(R):
+    for dims, pose in (((40, 24, 18), "z-"), ((17, 70, 9), "y+"), ((9, 9, 130), "x+"), ((70, 17, 33), "diag")):
+        sc = make_scene("cfg3", dims=dims, shade=1, pose=pose, f32=True)
+        sc.width, sc.height, sc.steps = 93, 61, 150
+        g, s0, s1, f0, f1 = _three(R, sc)
+        assert np.array_equal(s0, g) and np.array_equal(s1, g), (dims, pose)
