@@ -77,6 +77,9 @@ struct SlabParams {
 };
 
 #define SLAB_EPS 0.02f
+#ifndef SLAB_RUN_CAP
+#define SLAB_RUN_CAP 128  // longest run of empty layers a ray skips in one step (the set-up scans that far per entry)
+#endif
 // cache policy of the LDS-DMA stream ("" = default, " nt" = non-temporal); an experiment knob
 #ifndef SLAB_DMA_POLICY
 #define SLAB_DMA_POLICY ""
@@ -499,6 +502,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   // clear, which keeps bit 1 of both slices clear.
   if (Q.bricks != nullptr && npos > 0) {
     constexpr int BL = SMK_BRICK_LOG2;
+    const int psgn0 = dir > 0 ? 1 : -1;
     __syncthreads();
     auto extent = [&](int e, int &ulo, int &uhi, int &vlo, int &vhi) {
       const unsigned pk = wtab[e].pack;
@@ -543,6 +547,25 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       const bool mine = sl <= smax && !(wtab[e].base & 1);
       const bool below = sl - 1 >= smin && e - 1 >= 0 && !(wtab[e - 1].base & 1);
       if (!mine && !below) wtab[e].base |= 2;
+    }
+    // ... and an entry whose slice is not streamed needs no address: it holds, above the two bits, how many empty layers
+    // follow one another from this one on in marching order (capped; to the end of the tile's range = "the rest").  A ray
+    // whose sample falls into such a layer moves on to the first plane behind the run in one step (see the consumers).
+    __syncthreads();
+    for (int q = tid; q <= npos; q += NTH) {
+      const int sl = dir > 0 ? smin + q : smax + 1 - q;
+      const int e = sl - Q.Os;
+      if (e < 0 || e >= Q.Ds || sl > smax) continue;
+      if ((wtab[e].base & 3) != 3) continue;
+      int run = 1;
+      bool to_end = false;
+      for (; run < SLAB_RUN_CAP; ++run) {
+        const int s2 = sl + psgn0 * run;
+        if (s2 < smin || s2 > smax) { to_end = true; break; }
+        const int e2 = s2 - Q.Os;
+        if (e2 < 0 || e2 >= Q.Ds || !(wtab[e2].base & 1)) break;
+      }
+      wtab[e].base = ((to_end ? 0x7ffff : run) << 2) | 3;
     }
   }
   // every consumer wave announces the first position it needs before anyone moves on
@@ -872,6 +895,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       const bool count = DIAG && (P.lockstep & 48) != 0 && Q.diag != nullptr;
       float n_it = 0.f, n_act = 0.f, n_in = 0.f, n_hit = 0.f, n_anyhit = 0.f, n_lead = 0.f, n_waits = 0.f, n_wstep = 0.f;
       int have = 0;  // cached copy of `landed` (monotonic): re-polled only when a lane is blocked on it
+      const float inv_bs = 1.0f / B[AS];  // (planes per slice along this ray; the principal axis' B is never 0)
       // table row of the sample's base slice: entry index = bs - Os = psgn*pb + (-psgn*poff - Os)
       const int eoff = -psgn * poff - Q.Os;
       const unsigned wtab_addr = (unsigned)(size_t)(lds_cptr_t)wtab;
@@ -959,6 +983,28 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
         // EMPTY LAYERS: nothing in this sample's layer can be visible for any ray of the tile -- the sample is exactly
         // transparent, and its slices may not even have been streamed
         if (Q.bricks != nullptr) work = work && !(base_a & 1);
+        // the plane of this ray's next sample: the next one, or -- from a layer that starts a run of empty ones (the
+        // entry holds its length, see the set-up) -- the first plane whose base slice lies behind the run.  The planes
+        // in between fall into empty layers, all of them: positions are monotone in the plane index.
+        int m_next = m + 1;
+#ifndef SLAB_NO_JUMP
+        if (Q.bricks != nullptr && act && (base_a & 3) == 3) {
+          const int ptar = pb + (base_a >> 2);  // first position behind the run
+          if (ptar >= npos) m_next = m1 + 1;    // nothing but empty layers to the end of the tile's range
+          else {
+            // s(m) = fma(m, B, A) reaches the target slice at m = t; floor(t) is never behind the exact answer (the
+            // division is off by far less than a plane), the exact base slices of the planes from there on decide
+            const float starget = (float)(dir > 0 ? smin + ptar : smax - ptar + 1);
+            int mj = max((int)floorf((starget - A[AS]) * inv_bs), m + 1);
+#pragma unroll 1
+            for (int k = 0; k < 4 && mj <= m1; ++k) {
+              if (__mul24(psgn, base_slice(mj)) + poff >= ptar) break;
+              ++mj;
+            }
+            m_next = mj;
+          }
+        }
+#endif
         if (work) {
           const float mf = (float)m;
           // (no membership test: [m, m1] is exactly the inside interval, see the set-up)
@@ -986,8 +1032,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           float nsc = car_sc;
           int ni = car_i;
           if (act) {
-            if (m + 1 <= m1) {
-              ni = base_slice_c(m + 1, nsc);
+            if (m_next <= m1) {
+              ni = base_slice_c(m_next, nsc);
               pbn = __mul24(psgn, ni) + poff;
             } else pbn = SLAB_DONE;
           }
@@ -1190,7 +1236,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 #undef QI
         }
         if (act) {
-          ++m;
+          m = m_next;
           if constexpr (EARLY) {
             // (the next sample's slice was worked out when the ring slots were released; m1 may since have shrunk to m - 1
             //  -- the ray saturated -- which ends it)
