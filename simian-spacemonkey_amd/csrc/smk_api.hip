@@ -1019,10 +1019,11 @@ extern "C" int smk_frame_failed(smk_ctx *c, long long frame_id) {
 extern "C" int smk_get_stat(smk_ctx *c, const char *name, double *value) {
   if (!c || !name || !value) return 1;
   HIPCHK(c, hipSetDevice(c->device));
-  static const char *diag_names[14] = {"slab_iters", "slab_active_lanes", "slab_inside_lanes", "slab_hit_lanes",
+  static const char *diag_names[16] = {"slab_iters", "slab_active_lanes", "slab_inside_lanes", "slab_hit_lanes",
                                       "slab_loader_issue_kcyc", "slab_loader_wait_kcyc", "slab_loader_blocked_kcyc", "slab_loader_total_kcyc",
-                                      "slab_iters_with_hit", "slab_lead_sum", "slab_waits", "slab_wstep_sum", "slab_dead_tail_sum", "slab_waves"};
-  for (int k = 0; k < 14; ++k)
+                                      "slab_iters_with_hit", "slab_lead_sum", "slab_waits", "slab_wstep_sum", "slab_dead_tail_sum", "slab_waves",
+                                      "slab_iters_sampling", "slab_iters_own_brick"};
+  for (int k = 0; k < 16; ++k)
     if (!strcmp(name, diag_names[k])) {
       float v = 0.f;
       if (c->slab.d_diag) {
@@ -1061,6 +1062,23 @@ extern "C" int smk_get_stat(smk_ctx *c, const char *name, double *value) {
         pl += h[(size_t)nt + t];
       }
       if (pl > 0) *value = st / pl;
+    }
+    return 0;
+  }
+  // longest and summed workgroup durations of the latest slice-ring frame, in ms (the kernel's per-tile ticks); synchronises
+  if (!strcmp(name, "slab_tile_ms_max") || !strcmp(name, "slab_tile_ms_sum")) {
+    *value = 0.0;
+    const int nt = c->slab.ticks_n_last;
+    if (c->last_kernel == 2 && c->slab.d_ticks && nt > 0) {
+      HIPCHK(c, hipDeviceSynchronize());
+      std::vector<unsigned> h((size_t)nt);
+      HIPCHK(c, hipMemcpy(h.data(), c->slab.d_ticks, (size_t)nt * 4, hipMemcpyDeviceToHost));
+      double mx = 0, sum = 0;
+      for (int t = 0; t < nt; ++t) {
+        mx = std::max(mx, (double)h[t]);
+        sum += h[t];
+      }
+      *value = (name[13] == 'm' ? mx : sum) * 1e-5;  // 100 MHz ticks
     }
     return 0;
   }

@@ -555,8 +555,12 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
     for (int q = tid; q <= npos; q += NTH) {
       const int sl = dir > 0 ? smin + q : smax + 1 - q;
       const int e = sl - Q.Os;
-      if (e < 0 || e >= Q.Ds || sl > smax) continue;
+      if (e < 0 || e >= Q.Ds) continue;
       if ((wtab[e].base & 3) != 3) continue;
+      if (sl > smax) {  // (the slice behind the last layer)
+        wtab[e].base = (1 << 2) | 3;
+        continue;
+      }
       int run = 1;
       bool to_end = false;
       for (; run < SLAB_RUN_CAP; ++run) {
@@ -647,7 +651,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       //  column masks cached across slices in a VGPR bit set -- 1024^3 3.54 -> 3.74 ms: the scalar
       //  per-slice arithmetic below is cheaper than it looks, the extra VALU is not.)
       int ent_uv = 0, tab_base = -64;
-      int ent_skip = 0;  // ... and whether anybody needs the slice at all (EMPTY LAYERS, bit 1 of the entry's base)
+      int ent_run = 0;  // ... and, for a slice nobody needs, the length of the run of empty layers it starts (EMPTY LAYERS)
       int n_skipped = 0;
       // EAGER PUBLICATION.  A slice used to be published when its loader, done issuing the NEXT one, waited
       // for it -- up to a slice's issue time (~0.5 us) after it had landed, on a ring that is a few slices
@@ -685,6 +689,43 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
         bool stop = false;
         if (prof) t_mark = __builtin_amdgcn_s_memtime();
         while (q <= npos && inflight < Q.maxfly) {
+          if ((q & ~63) != tab_base) {  // (q steps by QSTEP: entering a new block of 64 load indices, not hitting its first one)
+            tab_base = q & ~63;
+            const int ql = tab_base + lane;
+            const int e = (dir > 0 ? smin + ql : smax + 1 - ql) - Q.Os;
+            ent_uv = -1;
+            ent_run = 0;
+            if (ql <= npos && e >= 0 && e < Q.Ds) {
+              const auto ent = raw_lds_b64(&wtab[e]);
+              ent_uv = (int)ent.y;  // (.pack; never -1: u0 < 2^11)
+              if (((int)ent.x & 3) == 3) ent_run = (int)ent.x >> 2;
+            }
+          }
+          // EMPTY LAYERS.  A slice nobody samples is not streamed, and a whole run of them is stepped over at once: the
+          // entry of an unneeded slice holds how many empty layers follow one another from its own on, and a slice between
+          // two empty layers is unneeded.  Nothing is written, so no ring room is asked for.  Slices in flight are waited
+          // for first when the run is long (their words are published in order); a short run behind slices in flight
+          // goes slice by slice below.
+          // (slice q + k lies between the layers of positions q + k - 1 and q + k when the march goes up the slice index,
+          //  q + k and q + k + 1 when it goes down: there the last slice of the run borders the layer behind it)
+          int run = Q.bricks != nullptr ? __builtin_amdgcn_readlane(ent_run, q & 63) : 0;
+          if (dir < 0 && run > 1) --run;
+          run = min(run, npos + 1 - q);
+          if (run > 0 && (inflight == 0 || run >= 8)) {
+            if (inflight > 0) {
+              wait_vmcnt(0);
+              landed += inflight * QSTEP;
+              inflight = 0;
+              if (FIFO) fly_total = 0;
+            }
+            const int mine = (run + QSTEP - 1) / QSTEP;  // my slices among q .. q + run - 1
+            if (gl == 0) n_skipped += mine;
+            q += mine * QSTEP;
+            landed = q;
+            raw_lds_st_b32(&ctl[(lid < 4 ? 4 : 20) + lid], landed);
+            slot_q = q % nslots;
+            continue;
+          }
           if (q - nslots >= minp) {
             minp = poll_progress();
             if (DIAG && (P.lockstep & 64)) minp = 0x3ffffff0;
@@ -694,23 +735,11 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             }
             if (q - nslots >= minp) break;
           }
-          if ((q & ~63) != tab_base) {  // (q steps by QSTEP: entering a new block of 64 load indices, not hitting its first one)
-            tab_base = q & ~63;
-            const int ql = tab_base + lane;
-            const int e = (dir > 0 ? smin + ql : smax + 1 - ql) - Q.Os;
-            ent_uv = -1;
-            ent_skip = 0;
-            if (ql <= npos && e >= 0 && e < Q.Ds) {
-              const auto ent = raw_lds_b64(&wtab[e]);
-              ent_uv = (int)ent.y;  // (.pack; never -1: u0 < 2^11)
-              ent_skip = ((int)ent.x >> 1) & 1;
-            }
-          }
           const int uv = __builtin_amdgcn_readlane(ent_uv, q & 63);
-          // a slice nobody samples is not streamed.  Small windows count on every slice being the same number of DMA
-          // instructions (the in-order vmcnt): there the slice may issue nothing only while none is in flight before it
-          // -- else it goes the uniform way with `mych` one-unit reads.
-          bool skip = Q.bricks != nullptr && __builtin_amdgcn_readlane(ent_skip, q & 63) != 0;
+          // Small windows count on every slice being the same number of DMA instructions (the in-order vmcnt): there an
+          // unneeded slice may issue nothing only while none is in flight before it -- else it goes the uniform way with
+          // `mych` one-unit reads.
+          bool skip = run > 0;
           if (!FIFO && inflight > 0) skip = false;
           if (skip && gl == 0) ++n_skipped;
           int issued = 0;  // DMA wave-instructions of this slice (this loader's share)
@@ -894,6 +923,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       if (DIAG && (P.lockstep & 64)) pb = SLAB_DONE;   // (diagnostic: free-running stream)
       const bool count = DIAG && (P.lockstep & 48) != 0 && Q.diag != nullptr;
       float n_it = 0.f, n_act = 0.f, n_in = 0.f, n_hit = 0.f, n_anyhit = 0.f, n_lead = 0.f, n_waits = 0.f, n_wstep = 0.f;
+      float n_work = 0.f, n_own = 0.f;
       int have = 0;  // cached copy of `landed` (monotonic): re-polled only when a lane is blocked on it
       const float inv_bs = 1.0f / B[AS];  // (planes per slice along this ray; the principal axis' B is never 0)
       // table row of the sample's base slice: entry index = bs - Os = psgn*pb + (-psgn*poff - Os)
@@ -964,7 +994,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           n_wstep += (float)Q.wstep;
         }
         asm volatile("" ::: "memory");  // slot reads stay behind the poll
-        bool d_hit = false;  // (diagnostic counters only)
+        bool d_hit = false, d_own = false;  // (diagnostic counters only)
         // ---- part A: where the sample is and its corner addresses; EARLY: the whole corner batch
         float fx = 0.f, fy = 0.f, fz = 0.f;
         unsigned a0 = 0, b0 = 0;
@@ -1019,6 +1049,9 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           else { z0 = car_i; fz = car_sc - (float)car_i; }
           (void)x1; (void)y1; (void)z1;
           const int iu = AU == 0 ? x0 : y0, iv = AV == 1 ? y0 : z0;  // global voxel indices
+          if (count && Q.bricks != nullptr)  // (diagnostic: would this lane's OWN brick have let it skip the sample?)
+            d_own = Q.bricks[(size_t)((car_i - Q.Os) >> SMK_BRICK_LOG2) * Q.bss + (size_t)((iv - Q.Ov) >> SMK_BRICK_LOG2) * Q.bsv +
+                             (size_t)((iu - Q.Ou) >> SMK_BRICK_LOG2) * Q.bsu] != 0;
           const unsigned lo_off = __umul24((unsigned)iv, pitch_b) + ((unsigned)iu << VBL);  // (24-bit multiply: full rate)
           a0 = (unsigned)base_a + lo_off;
           b0 = (unsigned)base_b + lo_off;
@@ -1256,6 +1289,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           n_in += (float)__popcll(__ballot(act));
           n_hit += (float)__popcll(__ballot(d_hit));
           n_anyhit += __any(d_hit) ? 1.f : 0.f;
+          n_work += __any(work) ? 1.f : 0.f;
+          n_own += __any(work && d_own) ? 1.f : 0.f;
         }
         }  // rep
       }
@@ -1267,6 +1302,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
         atomicAdd(&Q.diag[2], n_in);
         atomicAdd(&Q.diag[3], n_hit);
         atomicAdd(&Q.diag[8], n_anyhit);
+        atomicAdd(&Q.diag[14], n_work);
+        atomicAdd(&Q.diag[15], n_own);
         atomicAdd(&Q.diag[9], n_lead);
         atomicAdd(&Q.diag[10], n_waits);
         atomicAdd(&Q.diag[11], n_wstep);

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--u8", action="store_true")
     ap.add_argument("--synth", type=int, default=1, help="1 genvol spheres (bench input), 0 round 1's smooth shells")
     ap.add_argument("--variants", nargs="*", default=["kernel=1"])
+    ap.add_argument("--tf", default="", help="'clear': an all-transparent table (what a frame costs when nothing is sampled); 'opaque'")
     ap.add_argument("--shadow", default="", help="BUFFER,QUALITY: half-angle-slicing shadows with the light at (3,4,-3)")
     a = ap.parse_args()
     pkg = bench.load_package()
@@ -42,6 +43,11 @@ def main():
     del vghf, nrm
     torch.cuda.empty_cache()
     bench.configure(r, a.workload, n, a.size, a.planes)
+    if a.tf:
+        t = np.zeros((256, 256, 4), np.uint8)
+        if a.tf == "opaque":
+            t[:] = (200, 150, 100, 255)
+        r.set_tf2d(t, None)
     if a.pose.startswith("close"):
         # a close-up: strong perspective, rays far from the principal axis at the frame's edges
         dist = float(a.pose[5:] or 2.0)
@@ -81,11 +87,16 @@ def main():
         print("%-32s kernel=%d  %.3f ms/frame  (event avg %.3f ms)  %.1f GB/s alg  frac %.3f  maxdiff_vs_first %.2e  alpha_mean %.4f"
               % (var, kern, t / a.frames * 1e3, kms, alg / (kms * 1e-3) / 1e9, alg / (kms * 1e-3) / 1e9 / 8000, err, img[:, 3].mean()),
               flush=True)
+        if kern == 2:
+            print("   workgroups: longest %.3f ms, sum %.1f ms (= %.3f ms on every workgroup slot of 256 CUs x 2)" %
+                  (r.stat("slab_tile_ms_max"), r.stat("slab_tile_ms_sum"), r.stat("slab_tile_ms_sum") / 512), flush=True)
         if any(kv.split("=")[0] == "lockstep" and int(kv.split("=")[1]) & 16 for kv in var.split(",")):
             it, act, ins, hit = (r.stat(k) for k in ("slab_iters", "slab_active_lanes", "slab_inside_lanes", "slab_hit_lanes"))
             print("   consumer wave-iterations %.4g: lanes active %.1f%%, inside %.1f%%, hit %.1f%% of 64; iterations with a hit %.1f%%" %
                   (it, 100 * act / (64 * it + 1e-9), 100 * ins / (64 * it + 1e-9), 100 * hit / (64 * it + 1e-9),
                    100 * r.stat("slab_iters_with_hit") / (it + 1e-9)), flush=True)
+            print("   iterations that sample (some lane in a non-empty layer) %.1f%%; of those, with a lane whose OWN brick is flagged %.1f%%" %
+                  (100 * r.stat("slab_iters_sampling") / (it + 1e-9), 100 * r.stat("slab_iters_own_brick") / (r.stat("slab_iters_sampling") + 1e-9)), flush=True)
             print("   mean (landed - slowest lane) at step time %.2f slices; waits %.3g; mean wstep %.2f" %
                   (r.stat("slab_lead_sum") / (it + 1e-9), r.stat("slab_waits"), r.stat("slab_wstep_sum") / (it + 1e-9)), flush=True)
             print("   mean share of its tile's slice range a wave no longer needs when it finishes: %.1f%%" %
