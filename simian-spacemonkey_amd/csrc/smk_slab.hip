@@ -77,9 +77,6 @@ struct SlabParams {
 };
 
 #define SLAB_EPS 0.02f
-#ifndef SLAB_RUN_CAP
-#define SLAB_RUN_CAP 128  // longest run of empty layers a ray skips in one step (the set-up scans that far per entry)
-#endif
 // cache policy of the LDS-DMA stream ("" = default, " nt" = non-temporal); an experiment knob
 #ifndef SLAB_DMA_POLICY
 #define SLAB_DMA_POLICY ""
@@ -422,6 +419,9 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   }
   __syncthreads();
   const int smin = ctl[0], smax = ctl[1];
+  const bool phases = tracing && (P.lockstep & 128);  // (diagnostic: where the set-up's time goes, instead of the loader's cycles)
+  unsigned ph1 = 0, ph2 = 0, ph3 = 0;
+  if (phases) ph1 = (unsigned)__builtin_amdgcn_s_memrealtime() - trace_t0;
   const int dir = Q.dir, nslots = Q.nslots;
   const unsigned pitch_b = 16u * (unsigned)Q.wp;  // LDS row pitch in bytes
   const unsigned ring_addr = (unsigned)(size_t)(lds_cptr_t)smem;
@@ -494,15 +494,22 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       wtab[e] = ent;
     }
   }
+  if (phases) {
+    __syncthreads();
+    ph2 = (unsigned)__builtin_amdgcn_s_memrealtime() - trace_t0;
+  }
   // ---- EMPTY LAYERS.  The cells between slices b and b + 1 ("layer b") that this tile's rays can cross lie in the
   // overlap of the two slices' windows.  When every brick that overlap touches is flagged empty (smk_bricks.hip: no
   // sample in it can be visible under the current table), nobody in the tile samples layer b -- bit 0 of the entry --
   // and a slice whose two neighbouring layers are both empty is not streamed at all -- bit 1.  (The entries' base
   // addresses are multiples of 8.)  A sample that IS taken therefore finds both its slices loaded: its layer's bit 0 is
-  // clear, which keeps bit 1 of both slices clear.
+  // clear, which keeps bit 1 of both slices clear.  An entry whose slice is not streamed needs no address: it holds,
+  // above the two bits, how many empty layers follow one another from this one on in marching order (to the end of
+  // the tile's range = "the rest"); rays and loaders step over such a run at once (see there).
+  // Three steps, a barrier between them; the flags are read from memory once per layer of BRICKS, a lane per brick:
+  // (the first version read them per slice and thread, one after the other: 40 us per workgroup, a fifth of the frame)
   if (Q.bricks != nullptr && npos > 0) {
     constexpr int BL = SMK_BRICK_LOG2;
-    const int psgn0 = dir > 0 ? 1 : -1;
     __syncthreads();
     auto extent = [&](int e, int &ulo, int &uhi, int &vlo, int &vhi) {
       const unsigned pk = wtab[e].pack;
@@ -511,65 +518,96 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       uhi = ulo + (int)(((pk >> 22) & 0x3fu) + 1u) * UPV - 1;
       vhi = vlo + (Q.wv - (int)(pk >> 28) * ((Q.wv + 15) / 16)) - 1;
     };
-    for (int q = tid; q <= npos; q += NTH) {
-      const int sl = dir > 0 ? smin + q : smax + 1 - q;
-      const int e = sl - Q.Os;
-      if (e < 0 || e >= Q.Ds) continue;
-      bool none = true;
-      if (sl <= smax) {
-        int ulo, uhi, vlo, vhi;
-        extent(e, ulo, uhi, vlo, vhi);
-        if (e + 1 < Q.Ds) {  // (slice sl + 1 <= smax + 1 is in the tile's range: its entry is filled)
-          int u2, u3, v2, v3;
-          extent(e + 1, u2, u3, v2, v3);
-          ulo = max(ulo, u2);
-          uhi = min(uhi, u3);
-          vlo = max(vlo, v2);
-          vhi = min(vhi, v3);
-        }
-        // lower corners of the cells: one less than the voxels at the top end
-        uhi = min(uhi, Q.Du - 1) - 1;
-        vhi = min(vhi, Q.Dv - 1) - 1;
-        if (uhi >= ulo && vhi >= vlo) {
-          const unsigned char *row = Q.bricks + (size_t)(e >> BL) * Q.bss;
-          for (int bv = vlo >> BL; bv <= (vhi >> BL); ++bv)
-            for (int bu = ulo >> BL; bu <= (uhi >> BL); ++bu)
-              if (row[(size_t)bv * Q.bsv + (size_t)bu * Q.bsu]) none = false;
-        }
+    // (1) per layer of bricks along S: origin (first brick the tile's windows touch there) and the flags of the 8 x 8
+    // bricks from it on, as a 64-bit mask -- kept in the ring's memory, which nobody uses before the last barrier
+    uint4 *lmask = reinterpret_cast<uint4 *>(smem);
+    const int nlay = ((Q.Ds - 1) >> BL) + 1;
+    for (int bl0 = wave * 4; bl0 < nlay; bl0 += (NW + NL) * 4) {
+      int bu0[4], bv0[4];
+      unsigned f[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int bl = bl0 + k;
+        int ulo = 0x7fffffff, vlo = 0x7fffffff;
+        if (bl < nlay)
+          for (int e = bl << BL; e < min((bl + 1) << BL, Q.Ds); ++e) {
+            const int sl = e + Q.Os;
+            if (sl < smin || sl > smax + 1) continue;
+            const unsigned pk = wtab[e].pack;
+            ulo = min(ulo, (int)(pk & 0x7ffu));
+            vlo = min(vlo, (int)((pk >> 11) & 0x7ffu));
+          }
+        bu0[k] = ulo >> BL;
+        bv0[k] = vlo >> BL;
+        f[k] = 0;
+        const int bu = bu0[k] + (lane & 7), bv = bv0[k] + (lane >> 3);
+        if (ulo != 0x7fffffff && bu <= ((Q.Du - 1) >> BL) && bv <= ((Q.Dv - 1) >> BL))
+          f[k] = Q.bricks[(size_t)bl * Q.bss + (size_t)bv * Q.bsv + (size_t)bu * Q.bsu];
       }
-      if (none) wtab[e].base |= 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned long long m = __ballot(f[k] != 0);
+        if (lane == 0 && bl0 + k < nlay) lmask[bl0 + k] = make_uint4((unsigned)bu0[k], (unsigned)bv0[k], (unsigned)m, (unsigned)(m >> 32));
+      }
     }
     __syncthreads();
+    // (2) per slice: is its layer empty for this tile (bit 0), does anybody need the slice (bit 1)
+    auto layer_empty = [&](int sl) -> bool {  // layer sl, smin <= sl <= smax
+      const int e = sl - Q.Os;
+      int ulo, uhi, vlo, vhi;
+      extent(e, ulo, uhi, vlo, vhi);
+      if (e + 1 < Q.Ds) {  // (slice sl + 1 <= smax + 1 is in the tile's range: its entry is filled)
+        int u2, u3, v2, v3;
+        extent(e + 1, u2, u3, v2, v3);
+        ulo = max(ulo, u2);
+        uhi = min(uhi, u3);
+        vlo = max(vlo, v2);
+        vhi = min(vhi, v3);
+      }
+      // lower corners of the cells: one less than the voxels at the top end
+      uhi = min(uhi, Q.Du - 1) - 1;
+      vhi = min(vhi, Q.Dv - 1) - 1;
+      if (uhi < ulo || vhi < vlo) return true;
+      const uint4 L = lmask[e >> BL];
+      const int c0 = (ulo >> BL) - (int)L.x, c1 = (uhi >> BL) - (int)L.x, r0 = (vlo >> BL) - (int)L.y, r1 = (vhi >> BL) - (int)L.y;
+      if (c0 < 0 || r0 < 0 || c1 > 7 || r1 > 7) return false;  // (outside the square that was looked at: not known to be empty)
+      const unsigned long long cols = (unsigned long long)((0xffu >> (7 - c1)) & (0xffu << c0)) * 0x0101010101010101ull;
+      const unsigned long long rows = (~0ull >> (8 * (7 - r1))) & (~0ull << (8 * r0));
+      const unsigned long long m = (unsigned long long)L.z | ((unsigned long long)L.w << 32);
+      return (m & cols & rows) == 0;
+    };
     for (int q = tid; q <= npos; q += NTH) {
       const int sl = dir > 0 ? smin + q : smax + 1 - q;
       const int e = sl - Q.Os;
       if (e < 0 || e >= Q.Ds) continue;
-      const bool mine = sl <= smax && !(wtab[e].base & 1);
-      const bool below = sl - 1 >= smin && e - 1 >= 0 && !(wtab[e - 1].base & 1);
-      if (!mine && !below) wtab[e].base |= 2;
+      const bool mine = sl <= smax && !layer_empty(sl);
+      const bool below = sl - 1 >= smin && e - 1 >= 0 && !layer_empty(sl - 1);
+      int fl = mine ? 0 : 1;
+      if (!mine && !below) fl |= 2;
+      if (fl) wtab[e].base |= fl;
     }
-    // ... and an entry whose slice is not streamed needs no address: it holds, above the two bits, how many empty layers
-    // follow one another from this one on in marching order (capped; to the end of the tile's range = "the rest").  A ray
-    // whose sample falls into such a layer moves on to the first plane behind the run in one step (see the consumers).
     __syncthreads();
-    for (int q = tid; q <= npos; q += NTH) {
-      const int sl = dir > 0 ? smin + q : smax + 1 - q;
-      const int e = sl - Q.Os;
-      if (e < 0 || e >= Q.Ds) continue;
-      if ((wtab[e].base & 3) != 3) continue;
-      if (sl > smax) {  // (the slice behind the last layer)
-        wtab[e].base = (1 << 2) | 3;
-        continue;
+    // (3) run lengths, by one wave: 64 positions at a time from the far end, a ballot each (the run that starts at a
+    // position = the trailing ones of the mask from its bit on, + the next block's first run when it reaches the end)
+    if (wave == 0) {
+      int carry = 0x40000;  // behind the last position: "the rest"
+      for (int blk = (npos - 1) >> 6; blk >= 0; --blk) {
+        const int pq = (blk << 6) + lane;                  // position in marching order
+        const int sl = dir > 0 ? smin + pq : smax - pq;    // its layer
+        const int e = sl - Q.Os;
+        int bits = 3;                                      // (behind the range: counts as empty)
+        if (pq < npos) bits = (e >= 0 && e < Q.Ds) ? (wtab[e].base & 3) : 0;
+        const unsigned long long m = __ballot((bits & 1) != 0);
+        const unsigned long long rest = ~(m >> lane);      // (the shift brings in zeros: the count stops at the block's end)
+        int run = rest ? (int)__builtin_ctzll(rest) : 64;
+        if (run == 64 - lane) run += carry;
+        if (pq < npos && bits == 3) wtab[e].base = (min(run, 0x7ffff) << 2) | 3;
+        carry = __builtin_amdgcn_readlane(run, 0);
       }
-      int run = 1;
-      bool to_end = false;
-      for (; run < SLAB_RUN_CAP; ++run) {
-        const int s2 = sl + psgn0 * run;
-        if (s2 < smin || s2 > smax) { to_end = true; break; }
-        const int e2 = s2 - Q.Os;
-        if (e2 < 0 || e2 >= Q.Ds || !(wtab[e2].base & 1)) break;
+      if (lane == 0) {  // the slice behind the last layer (no layer of its own)
+        const int e = smax + 1 - Q.Os;
+        if (e >= 0 && e < Q.Ds && (wtab[e].base & 3) == 3) wtab[e].base = (1 << 2) | 3;
       }
-      wtab[e].base = ((to_end ? 0x7ffff : run) << 2) | 3;
     }
   }
   // every consumer wave announces the first position it needs before anyone moves on
@@ -585,6 +623,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
     if (lane == 0) ctl[8 + wave] = pos;
   }
   __syncthreads();  // table, alpha_H, control words visible; LAST workgroup barrier
+  if (phases) ph3 = (unsigned)__builtin_amdgcn_s_memrealtime() - trace_t0;
   float C0 = 0.f, C1 = 0.f, C2 = 0.f, C3 = 0.f;
 
   if (npos > 0) {
@@ -888,7 +927,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 #undef SLAB_DMA
       wait_vmcnt(0);
       if (n_skipped && lane == 0) atomicAdd(&ctl[2], n_skipped);
-      if (tracing && lane == 0 && lid == 0) {
+      if (tracing && !phases && lane == 0 && lid == 0) {
         unsigned *t = Q.trace + 8 * (size_t)blockIdx.x;
         t[4] = (unsigned)(t_issue >> 6);
         t[5] = (unsigned)(t_wait >> 6);
@@ -1331,6 +1370,11 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   }
   if (tracing && tid == 0) {
     unsigned *t = Q.trace + 8 * (size_t)blockIdx.x;
+    if (phases) {  // 100 MHz ticks since the workgroup started: slice range known | windows tabled | flags, runs, last barrier
+      t[4] = ph1;
+      t[5] = ph2;
+      t[6] = ph3;
+    }
     t[0] = trace_t0;
     t[1] = (unsigned)__builtin_amdgcn_s_memrealtime();
     t[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
@@ -1822,6 +1866,8 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     if (opt_ns >= 3 && ns > opt_ns) ns = opt_ns;  // (experiment knob: cap the ring)
     if (ns < 3) { if (ci + 1 < nlist) continue; *why = "window does not fit LDS"; return hipErrorNotSupported; }
     Q.nslots = ns;
+    // (the set-up keeps a 16-byte brick mask per layer of bricks in the ring's memory before the stream starts)
+    if (Q.bricks && (size_t)ns * Q.slot_bytes < ((size_t)((Q.Ds - 1) >> SMK_BRICK_LOG2) + 1) * 16) Q.bricks = nullptr;
     const int mych = (Q.groups + lpg - 1) / lpg * Q.per;  // most DMA instructions one loader issues per slice
     // Slices a loader keeps in flight.  TWO: a loader publishes a slice as landed only when it stops
     // issuing and waits for the oldest one, so a deep issue window delays every consumer that polls

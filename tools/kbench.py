@@ -74,8 +74,12 @@ def main():
         for kv in var.split(","):
             k, v = kv.split("=")
             r.set_option(k, int(v))
-        with torch.cuda.stream(work):
-            t, kms, kn = bench.timed(r, a.frames, 2, frame, 1, None)
+        try:
+            with torch.cuda.stream(work):
+                t, kms, kn = bench.timed(r, a.frames, 2, frame, 1, None)
+        except Exception as ex:  # (a forced configuration the launcher refuses: say so, go on with the next variant)
+            print("%-32s refused: %s" % (var, str(ex).strip().splitlines()[-1][:150]), flush=True)
+            continue
         kern, _, alg = r.last_frame_info()
         img = frame.cpu().numpy()
         st = r.stat("slab_status")
@@ -118,6 +122,9 @@ def main():
             sh = (tr[:, 2] >> 12) & 1
             xcc = tr[:, 3] & 0xf
             key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+            if any(kv.split("=")[0] == "lockstep" and int(kv.split("=")[1]) & 128 for kv in var.split(",")):
+                print("   set-up phases, mean us since workgroup start: slice range %.1f | windows tabled %.1f | flags + runs + last barrier %.1f | end %.1f" %
+                      (tr[:, 4].mean() / 100.0, tr[:, 5].mean() / 100.0, tr[:, 6].mean() / 100.0, dur.mean()))
             print("   trace: %d workgroups on %d distinct (xcc,se,sh,cu); frame span %.1f us; WG duration min/mean/max %.1f/%.1f/%.1f us"
                   % (len(tr), len(np.unique(key)), (t1.max() - base_t) / 100.0, dur.min(), dur.mean(), dur.max()))
             busy = {}
