@@ -238,10 +238,33 @@ def roofline(r, kms, alg_bytes, size, note=None, traffic=None):
                              "on this code (counters cannot be read in-process)" if traffic is not None else None,
            "kernel_ms": kms,
            "algorithmic_bytes_per_launch": net, "algorithmic_bytes_if_every_slice_streamed": alg_bytes,
-           "slices_streamed_fraction": streamed}
+           "slices_streamed_fraction": streamed,
+           # SURVEY 8(d)'s formula (every stored voxel once) over the same time: NOT a bandwidth once bricks that cannot
+           # hold a visible sample are skipped (option "bricks", smk_bricks.hip) -- it can exceed the HBM peak
+           "each_voxel_once_GBps": alg_bytes / (kms * 1e-3) / 1e9 if kms > 0 else 0.0}
     if note:
         out["note"] = note
     return out
+
+
+def no_flags_leg(r, work, frame, size, planes, steps):
+    """The same frame with empty-space skipping off (option "bricks" 0): every slice of every tile is streamed and every
+    sample interpolated and classified -- the streaming kernel's own roofline.  The frames are bit-identical
+    (tests/test_gpu_bricks.py); the flags only remove work whose result is exactly transparent."""
+    K = max(3, min(steps, 10))
+    keep = frame.clone()
+    r.set_option("bricks", 0)
+    with torch.cuda.stream(work):
+        t, kms, kn = timed(r, K, 2, frame, 1, None)
+    kernel, _, alg = r.last_frame_info()
+    rl = roofline(r, kms, alg, size)
+    same = bool(torch.equal(keep, frame))
+    r.set_option("bricks", 1)
+    with torch.cuda.stream(work):      # back to the product's default, schedule settled again
+        timed(r, 2, 2, frame, 1, None)
+    return {"ms_per_frame": t / K * 1e3, "Msamples_per_s": float(size) * size * planes / (t / K) / 1e6,
+            "kernel": {1: "gather", 2: "slab-staged"}.get(kernel, str(kernel)), "roofline": rl,
+            "frame_bit_identical_to_the_one_with_flags": same}
 
 
 def libc_noise_tex(n=32):
@@ -500,6 +523,10 @@ def main():
     dev = local if world > 1 else 0
     torch.cuda.set_device(dev)
     r = pkg.Renderer(dev)            # raises when the HIP library / device is missing
+    # (profiling only: SMK_BENCH_BRICKS=0 runs every leg with empty-space skipping off -- the streaming kernel's own counters)
+    flags_on = os.environ.get("SMK_BENCH_BRICKS", "1") != "0"
+    if not flags_on:
+        r.set_option("bricks", 0)
     r.set_option("kernel", a.kernel)
 
     n, size, planes = a.volume, a.size, a.planes
@@ -595,6 +622,8 @@ def main():
         out["roofline"]["kernel_frames_timed"] = kn
         if default_workload and world == 1:
             out["roofline_valu"] = roofline_valu(kms, "cfg3")
+        if world == 1 and not a.no_extra and flags_on:
+            out["without_brick_flags"] = no_flags_leg(r, work, frame, size, planes, a.steps)
     failures = int(r.stat("slab_failures"))
     if world > 1:
         out["rccl_ranks"] = 0 if rehearse else world
@@ -650,6 +679,8 @@ def main():
             "workload": "cfg4 single GPU: %d^3 f32 VGH + u8 normals, (v,g)x(h) TF, R8k Phong, %dx%dx%d" % (nn_, size, size, planes),
             "ms_per_frame": t2 / k2 * 1e3, "fps": k2 / t2, "Msamples_per_s": samples / (t2 / k2) / 1e6,
             "roofline": rl2, "kernel": {1: "gather", 2: "slab-staged"}.get(kernel2, str(kernel2))}
+        if not a.no_extra and flags_on:
+            out["north_star"]["without_brick_flags"] = no_flags_leg(r, work, frame, size, planes, a.steps)
         if not a.no_cpu:
             # parity of the north-star frame itself: the CPU checker on 200 random rays of it
             torch.cuda.synchronize()
@@ -660,6 +691,8 @@ def main():
         if not a.no_extra:
             out["extra"] = extra_legs(r, frame, work, a.steps)
     bad = out["slab_failures"] != 0 or r.stat("slab_retries") != 0
+    if not flags_on:
+        out["data"] += "; SMK_BENCH_BRICKS=0: empty-space skipping off (a profiling run, not the product's default)"
     if rank == 0:
         print(json.dumps(out))
     if world > 1 and cstate is not None and hasattr(cstate[0], "x"):

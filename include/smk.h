@@ -261,6 +261,9 @@ int smk_get_light_buffer(smk_ctx *ctx, float *rgba_out, int *lb_out);
  *              mode); 2 slice-ring kernel (fails where it does not apply, with the reason)
  *   "tf_raw"   [0] 1: the 2-D table handed to smk_set_tf2d is already opacity-corrected (copyScale off)
  *   "halo"     [1] voxels of halo kept around a shard's region (before smk_upload_volume)
+ *   "bricks"   [1] empty-space skipping: 8x8x8-cell bricks in which no sample can be visible under the current
+ *              table are neither streamed nor sampled (the skipped samples are exactly transparent: frames are
+ *              bit-identical with 0 and 1); 0 = every sample is fetched and classified
  *   developer knobs: "tile" (slice-ring workgroup shape id), "slab_T" (band wait + 1), "slab_fly"
  *   (slices a loader keeps in flight), "slab_ns" (cap on the ring's slots), "lockstep" (bit 0 gather lockstep; bits 1..6 slice-ring
  *   diagnostics, see tools/kbench.py), "wave_w"/"blk_w" (gather tile shape), "inject_slab_status"

@@ -845,6 +845,7 @@ static int refresh_tf2d(smk_ctx *c, const smk_raycoef &rc, hipStream_t s) {
   // bilinear lookup with base texel (s, t) touches has alpha != 0.  A clear bit means the lookup
   // returns alpha == 0 EXACTLY (lerps of zeros), so a kernel may skip the fetch without changing
   // a single bit of the frame.
+  size_t occ_set = 0;
   {
     uint32_t *occ = reinterpret_cast<uint32_t *>(T.h + n * 4);
     memset(occ, 0, occ_words * 4);
@@ -854,7 +855,7 @@ static int refresh_tf2d(smk_ctx *c, const smk_raycoef &rc, hipStream_t s) {
         const int s1 = std::min(sx + 1, sv - 1), t1 = std::min(t + 1, sg - 1);
         if (e[((size_t)t * sv + sx) * 4 + 3] | e[((size_t)t * sv + s1) * 4 + 3] | e[((size_t)t1 * sv + sx) * 4 + 3] |
             e[((size_t)t1 * sv + s1) * 4 + 3])
-          occ[(size_t)t * roww + (sx >> 5)] |= 1u << (sx & 31);
+          occ[(size_t)t * roww + (sx >> 5)] |= 1u << (sx & 31), ++occ_set;
       }
   }
   if (T.used_valid) HIPCHK(c, hipStreamWaitEvent(s, T.used, 0));  // the last frame that read this version is done
@@ -864,7 +865,10 @@ static int refresh_tf2d(smk_ctx *c, const smk_raycoef &rc, hipStream_t s) {
   c->d_tf_vg = reinterpret_cast<uint32_t *>(T.d);
   c->d_tf_occ = reinterpret_cast<uint32_t *>(T.d + n * 4);
   // this version's brick flags (smk_bricks.hip), behind the copy on the same stream: two small launches per refresh
-  if (c->opt_bricks && c->d_brick_mm) {
+  // (a table that is opaque nearly everywhere flags every brick: the flags would only cost their set-up)
+  T.bricks_valid = false;
+  if (c->opt_bricks && c->d_brick_mm && occ_set * 10 <= n * 9) {
+    T.bricks_valid = true;
     const size_t nbricks = (size_t)c->nbr[0] * c->nbr[1] * c->nbr[2], sat_words = (size_t)(sv + 1) * (sg + 1);
     if (T.bricks_cap < nbricks) {  // (a new volume size: rare; hipFree waits for the frames in flight)
       if (T.bricks) (void)hipFree(T.bricks);
@@ -1180,7 +1184,7 @@ static int build_params(smk_ctx *c, RenderParams &P, hipStream_t s) {
   P.bricks = nullptr;
   for (int a = 0; a < 3; ++a) P.nbr[a] = c->nbr[a];
   if (c->opt_bricks && c->d_brick_mm) {
-    if (c->tf_mode == 1 && c->tf_cur >= 0) P.bricks = c->tfv[c->tf_cur].bricks;
+    if (c->tf_mode == 1 && c->tf_cur >= 0 && c->tfv[c->tf_cur].bricks_valid) P.bricks = c->tfv[c->tf_cur].bricks;
     if (c->tf_mode == 2 && c->d_tf3d_occ) {
       if (c->bricks3_dirty || !c->d_bricks3) {
         HIPCHK(c, hipDeviceSynchronize());  // (a new table or volume: rare; frames in flight may still read the old flags)

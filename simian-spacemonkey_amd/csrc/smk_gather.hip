@@ -118,6 +118,11 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
     y1 = min(max(y1 - P.O[1], 0), P.D[1] - 1);
     z0 = min(max(z0 - P.O[2], 0), P.D[2] - 1);
     z1 = min(max(z1 - P.O[2], 0), P.D[2] - 1);
+    // brick flags (smk_bricks.hip): no sample whose cell lies in a brick with a clear flag can be visible under the
+    // current table -- it ends at a clear occupancy bit below, alpha exactly 0 -- so its eight corners are not fetched
+    if (TF != 0 && P.bricks != nullptr &&
+        !P.bricks[((size_t)(z0 >> SMK_BRICK_LOG2) * P.nbr[1] + (size_t)(y0 >> SMK_BRICK_LOG2)) * P.nbr[0] + (size_t)(x0 >> SMK_BRICK_LOG2)])
+      continue;
     size_t r00 = ((size_t)z0 * Dy + y0) * Dx, r10 = ((size_t)z0 * Dy + y1) * Dx;
     size_t r01 = ((size_t)z1 * Dy + y0) * Dx, r11 = ((size_t)z1 * Dy + y1) * Dx;
     const size_t c0 = (size_t)x0, c1 = (size_t)x1;

@@ -158,6 +158,7 @@ struct smk_ctx {
     unsigned char *bricks = nullptr;            // this version's brick flags (smk_bricks.hip) + the summed-area table they
     uint32_t *sat = nullptr;                    // were made from; sized for the volume / the table when first needed
     size_t bricks_cap = 0, sat_cap = 0;
+    bool bricks_valid = false;                  // (not made for a table that is opaque nearly everywhere)
     size_t cap = 0;
     hipEvent_t copied = nullptr, used = nullptr;
     bool used_valid = false;

@@ -104,6 +104,18 @@ __device__ __forceinline__ void shadow_lookup(const float4 *L, int LB, float lx,
   out[2] = smk_lerp(smk_lerp(t[0].z, t[1].z, fx), smk_lerp(t[2].z, t[3].z, fx), fy);
 }
 
+// brick flags (smk_bricks.hip): a sample whose cell lies in a brick with a clear flag is exactly transparent under the
+// current table -- nothing for the eye, nothing for the light buffer -- so its eight corners are not fetched
+__device__ __forceinline__ bool shadow_brick_empty(const RenderParams &P, float p0, float p1, float p2) {
+  if (P.bricks == nullptr) return false;
+  int x0, x1, y0, y1, z0, z1;
+  float fx, fy, fz;
+  smk_lin_clamp(p0, P.N[0], x0, x1, fx);
+  smk_lin_clamp(p1, P.N[1], y0, y1, fy);
+  smk_lin_clamp(p2, P.N[2], z0, z1, fz);
+  return !P.bricks[((size_t)(z0 >> SMK_BRICK_LOG2) * P.nbr[1] + (size_t)(y0 >> SMK_BRICK_LOG2)) * P.nbr[0] + (size_t)(x0 >> SMK_BRICK_LOG2)];
+}
+
 template <int DT, int TF, int SH>
 __global__ __launch_bounds__(256) void smk_k_shadow_slice(const RenderParams P, const ShadowSlice Q) {
   const smk_shadowcoef &sc = Q.sc;
@@ -130,6 +142,7 @@ __global__ __launch_bounds__(256) void smk_k_shadow_slice(const RenderParams P, 
     const size_t o = (size_t)j * P.W + i;
     float4 C = P.out[o];
     if (sc.front_to_back && C.w == 1.0f) return;  // exact: every later weight (1-A) is 0
+    if (shadow_brick_empty(P, p[0], p[1], p[2])) return;
     float ch0, ch1, ch2, ch3, n0 = 0.f, n1 = 0.f, n2 = 0.f;
     shadow_fetch<DT, TF, SH != 0>(P, p[0], p[1], p[2], ch0, ch1, ch2, ch3, n0, n1, n2);
     float4 col;
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(256) void smk_k_shadow_slice(const RenderParams P, 
       p[q] = __fmaf_rn(w, G, sc.Lc[q]);
       in = in && p[q] >= -0.5f && p[q] <= (float)P.N[q] - 0.5f;
     }
-    if (in) {
+    if (in && !shadow_brick_empty(P, p[0], p[1], p[2])) {
       float ch0, ch1, ch2, ch3, n0, n1, n2;
       shadow_fetch<DT, TF, false>(P, p[0], p[1], p[2], ch0, ch1, ch2, ch3, n0, n1, n2);
       float4 col;

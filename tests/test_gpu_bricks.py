@@ -20,13 +20,13 @@ def R(gpu_renderer_factory):
 
 
 def _three(R, sc, grid=(1, 1, 1)):
-    """frames of: gather kernel, slice ring without flags, slice ring with flags (+ streamed fractions)"""
-    R.set_option("bricks", 1)
+    """frames of: gather kernel WITHOUT the flags (the reference the others must equal), slice ring without flags,
+    slice ring with flags (+ streamed fractions); the gather kernel with the flags is checked on the way"""
+    R.set_option("bricks", 0)
     push_scene(R, sc, grid)
     R.set_option("kernel", 1)
     g = R.render()
     R.set_option("kernel", 2)
-    R.set_option("bricks", 0)
     s0 = R.render()
     assert R.last_frame_info()[0] == 2
     f0 = R.stat("slab_streamed_fraction")
@@ -34,6 +34,9 @@ def _three(R, sc, grid=(1, 1, 1)):
     s1 = R.render()
     assert R.last_frame_info()[0] == 2
     f1 = R.stat("slab_streamed_fraction")
+    R.set_option("kernel", 1)
+    g1 = R.render()
+    assert np.array_equal(g1, g), "gather kernel: the flags changed the frame"
     R.set_option("kernel", 0)
     assert R.stat("slab_failures") == 0
     return g, s0, s1, f0, f1
@@ -109,3 +112,47 @@ def test_ragged_and_thin(R):
         sc.width, sc.height, sc.steps = 93, 61, 150
         g, s0, s1, f0, f1 = _three(R, sc)
         assert np.array_equal(s0, g) and np.array_equal(s1, g), (dims, pose)
+
+
+def test_depth_and_clip_plane_frames_on_the_gather_kernel(R):
+    """frames only the gather kernel renders (first-hit depth, a free clip plane): flags on == flags off, depth included"""
+    sc = make_scene("cfg3", n=64, size=96, steps=128, pose="rot", f32=True, shade=1)
+    n = np.array([0.35, -0.2, -0.9])
+    n /= np.linalg.norm(n)
+    mv = np.array(sc.mv(), np.float64).reshape(4, 4).T   # column-major -> rows
+    centre = mv @ np.array([float(sc.fsize[0]) / 2, float(sc.fsize[1]) / 2, float(sc.fsize[2]) / 2, 1.0])
+    sc.clip_plane = (n[0], n[1], n[2], -float(n @ centre[:3]) + 0.03)   # through (almost) the volume's middle
+    out = {}
+    for b in (0, 1):
+        R.set_option("bricks", b)
+        push_scene(R, sc)
+        R.set_option("kernel", 0)
+        out[b] = R.render(depth=True)
+        assert R.last_frame_info()[0] == 1
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+    assert out[0][0][..., 3].max() > 0.05
+    sc.clip_plane = None
+    push_scene(R, sc)
+    R.set_option("bricks", 1)
+
+
+@pytest.mark.parametrize("f32", [False, True])
+def test_shadow_frames(R, f32):
+    """half-angle slicing: the eye pass and the light pass skip the same transparent samples -- frame and light buffer
+    bit for bit with the flags on and off"""
+    sc = make_scene("cfg3", n=64, size=96, steps=128, f32=f32, shade=1)
+    sc.light_pos = (3, 4, -3)
+    sc.shadow = (128, 0.5)
+    out = {}
+    for b in (0, 1):
+        R.set_option("bricks", b)
+        push_scene(R, sc)
+        frame = R.render()
+        assert R.last_frame_info()[0] == 3
+        out[b] = (frame, R.light_buffer())
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert out[0][0][..., 3].max() > 0.05 and out[0][1][..., 3].max() > 0.05
+    sc.shadow = None
+    push_scene(R, sc)
+    R.set_option("bricks", 1)
