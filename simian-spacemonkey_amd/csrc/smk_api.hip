@@ -87,7 +87,8 @@ extern "C" void smk_destroy(smk_ctx *c) {
     if (T.copied) (void)hipEventDestroy(T.copied);
     if (T.used) (void)hipEventDestroy(T.used);
   }
-  void *ptrs[] = {c->d_bricks3, c->d_sat3, c->d_tlut, c->d_tf_h, c->d_tf3d, c->d_tf3d_occ, c->d_noise, c->d_out, c->d_depth, c->d_light[0], c->d_light[1]};
+  if (c->tf_raw_ev) (void)hipEventDestroy(c->tf_raw_ev);
+  void *ptrs[] = {c->d_tf_raw, c->d_bricks3, c->d_sat3, c->d_tlut, c->d_tf_h, c->d_tf3d, c->d_tf3d_occ, c->d_noise, c->d_out, c->d_depth, c->d_light[0], c->d_light[1]};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->slab.h_status) (void)hipHostFree(c->slab.h_status);
@@ -371,6 +372,16 @@ extern "C" int smk_set_tf2d(smk_ctx *c, const unsigned char *deptex, const unsig
   if (!deptex || sv < 2 || sg < 1) FAIL(c, "smk_set_tf2d: bad table");
   size_t bytes = (size_t)sv * sg * 4;
   c->h_tf_vg.assign(deptex, deptex + bytes);
+  c->tf_raw_stale = true;
+  // histogram of the largest alpha of every 2 x 2 texel quad (refresh_tf2d: how much of the table a correction rate leaves occupied)
+  memset(c->tf_quad_hist, 0, sizeof c->tf_quad_hist);
+  for (int t = 0; t < sg; ++t)
+    for (int sx = 0; sx < sv; ++sx) {
+      const int s1 = std::min(sx + 1, sv - 1), t1 = std::min(t + 1, sg - 1);
+      const unsigned char m = std::max(std::max(deptex[((size_t)t * sv + sx) * 4 + 3], deptex[((size_t)t * sv + s1) * 4 + 3]),
+                                       std::max(deptex[((size_t)t1 * sv + sx) * 4 + 3], deptex[((size_t)t1 * sv + s1) * 4 + 3]));
+      ++c->tf_quad_hist[m];
+    }
   if (deptex2) {
     c->h_tf_h.assign(deptex2, deptex2 + bytes);
     if (dev_replace(c, &c->d_tf_h, deptex2, bytes)) return 1;
@@ -797,23 +808,58 @@ static void shading_vectors(const smk_ctx *c, RenderParams &P) {
 // NV20VolRen3D::copyScale (:1645-1660) with the rate the renderer would pass (:94-98, :117)
 // The effective (V,G) table of a frame: opacity correction as copyScale does it, plus the occupancy bitmap.  In steps
 // mode the correction rate follows the view-depth extent, i.e. it changes with every camera move: the table is then
-// rebuilt per frame, so the rebuild must not stall the pipeline -- a 256-entry map of the alpha byte (the correction is a
-// function of that byte alone; same arithmetic), and four versions on the device filled by stream-ordered copies from
-// pinned staging (a version is rewritten only after the last frame that read it: an event wait ON THE STREAM, not on the
-// host).  Before: hipFree + hipMalloc + hipMemcpy per refresh = a device synchronisation and 1.6 ms of pow() per frame.
-static int refresh_tf2d(smk_ctx *c, const smk_raycoef &rc, hipStream_t s) {
-  if (c->tf_mode != 1) return 0;
-  float sr;
+// rebuilt per frame, so the rebuild must neither stall the pipeline nor cost the host much.  The correction is a function
+// of the alpha byte alone (a 256-entry map, same arithmetic as copyScale), so the host computes that map and a kernel
+// applies it to the raw table kept on the device, writing the effective table and its bitmap into one of four versions
+// (a version is rewritten only after the last frame that read it: an event wait ON THE STREAM, not on the host).
+// Round 2 before: hipFree + hipMalloc + hipMemcpy per refresh = a device synchronisation and 1.6 ms of pow() per frame;
+// then 65536 map look-ups + the bitmap on the host (0.4 ms per moving-camera frame, more than the launcher's planning).
+__global__ __launch_bounds__(256) void smk_k_tf_effective(const uint32_t *raw, const unsigned char *map, int sv, int sg, int roww,
+                                                           uint32_t *eff, uint32_t *occ) {
+  // a wave = 64 consecutive texels of one row: its two bitmap words come from one ballot
+  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  const int wpr = (sv + 63) / 64;  // waves per row
+  const int t = wave / wpr, s = (wave - t * wpr) * 64 + lane;
+  if (t >= sg) return;
+  bool any = false;
+  if (s < sv) {
+    const int s1 = min(s + 1, sv - 1), t1 = min(t + 1, sg - 1);
+    const uint32_t a = raw[(size_t)t * sv + s];
+    const unsigned ma = map[a >> 24];
+    eff[(size_t)t * sv + s] = (a & 0x00ffffffu) | (ma << 24);
+    any = (ma | map[raw[(size_t)t * sv + s1] >> 24] | map[raw[(size_t)t1 * sv + s] >> 24] | map[raw[(size_t)t1 * sv + s1] >> 24]) != 0;
+  }
+  const unsigned long long m = __ballot(any);
+  const int w0 = (s - lane) >> 5;
+  if (lane == 0 && w0 < roww) occ[(size_t)t * roww + w0] = (uint32_t)m;
+  if (lane == 32 && w0 + 1 < roww) occ[(size_t)t * roww + w0 + 1] = (uint32_t)(m >> 32);
+}
+
+static float tf2d_rate(const smk_ctx *c, const smk_raycoef &rc) {
   if (c->scale_alphas) {
     float rate = c->steps > 0 ? (float)(c->fsize[0] / ((double)c->N[0] * (double)rc.dis)) : c->sample_rate;
-    sr = rate * 1 / c->gamma;
-  } else {
-    sr = 1 / c->gamma;
+    return rate * 1 / c->gamma;
   }
+  return 1 / c->gamma;
+}
+
+// NV20VolRen3D::copyScale (:1645-1660) per possible alpha byte
+static void tf2d_alpha_map(const smk_ctx *c, float sr, unsigned char map[256]) {
+  if (c->opt_tf_raw) {
+    for (int a = 0; a < 256; ++a) map[a] = (unsigned char)a;
+    return;
+  }
+  const float alphaScale = (float)(1.0 / sr);
+  for (int a = 0; a < 256; ++a) map[a] = (unsigned char)(int)((1.0 - pow((1.0 - (a / 255.0)), alphaScale)) * 255);
+}
+
+static int refresh_tf2d(smk_ctx *c, const smk_raycoef &rc, hipStream_t s) {
+  if (c->tf_mode != 1) return 0;
+  const float sr = tf2d_rate(c, rc);
   if (!c->tf_dirty && sr == c->tf_rate_applied && c->d_tf_vg) return 0;
   const size_t n = (size_t)c->sv * c->sg;
   const int sv = c->sv, sg = c->sg, roww = (sv + 31) / 32;
-  const size_t occ_words = (size_t)roww * sg, bytes = n * 4 + occ_words * 4;
+  const size_t occ_words = (size_t)roww * sg, bytes = n * 4 + occ_words * 4 + 256;  // table | bitmap | alpha map
   const int v = (c->tf_cur + 1) & 3;
   smk_ctx::TfVersion &T = c->tfv[v];
   if (T.cap < bytes) {  // (a new table size: rare)
@@ -831,40 +877,56 @@ static int refresh_tf2d(smk_ctx *c, const smk_raycoef &rc, hipStream_t s) {
     if (!T.used) HIPCHK(c, hipEventCreateWithFlags(&T.used, hipEventDisableTiming));
     T.used_valid = false;
   } else if (T.copied) {
-    HIPCHK(c, hipEventSynchronize(T.copied));  // the staging buffer's previous copy (four refreshes ago) has run
+    HIPCHK(c, hipEventSynchronize(T.copied));  // the staging buffer's previous copies (four refreshes ago) have run
   }
-  c->h_tf_eff = c->h_tf_vg;
-  if (!c->opt_tf_raw) {
-    float alphaScale = (float)(1.0 / sr);
-    unsigned char map[256];  // NV20VolRen3D::copyScale (:1645-1660) per possible alpha byte
-    for (int a = 0; a < 256; ++a) map[a] = (unsigned char)(int)((1.0 - pow((1.0 - (a / 255.0)), alphaScale)) * 255);
-    for (size_t i = 0; i < n; ++i) c->h_tf_eff[i * 4 + 3] = map[c->h_tf_vg[i * 4 + 3]];
+  // the raw table lives on the device; a new one travels through this version's staging buffer
+  if (c->tf_raw_cap < n * 4) {
+    HIPCHK(c, hipDeviceSynchronize());
+    if (c->d_tf_raw) (void)hipFree(c->d_tf_raw);
+    c->d_tf_raw = nullptr;
+    c->tf_raw_cap = 0;
+    HIPCHK(c, hipMalloc((void **)&c->d_tf_raw, n * 4));
+    c->tf_raw_cap = n * 4;
+    c->tf_raw_stale = true;
   }
-  memcpy(T.h, c->h_tf_eff.data(), n * 4);
-  // occupancy bitmap of the effective table: bit (t, s) is set when any of the four texels a
-  // bilinear lookup with base texel (s, t) touches has alpha != 0.  A clear bit means the lookup
-  // returns alpha == 0 EXACTLY (lerps of zeros), so a kernel may skip the fetch without changing
-  // a single bit of the frame.
+  if (!c->tf_raw_ev) HIPCHK(c, hipEventCreateWithFlags(&c->tf_raw_ev, hipEventDisableTiming));
+  if (c->tf_raw_stale) {
+    memcpy(T.h, c->h_tf_vg.data(), n * 4);
+    if (c->tf_raw_ev_valid) HIPCHK(c, hipStreamWaitEvent(s, c->tf_raw_ev, 0));  // the last kernel that read the old raw table is done
+    HIPCHK(c, hipMemcpyAsync(c->d_tf_raw, T.h, n * 4, hipMemcpyHostToDevice, s));
+    c->tf_raw_stale = false;
+  }
+  unsigned char *map = T.h + n * 4 + occ_words * 4;
+  tf2d_alpha_map(c, sr, map);
+  if (T.used_valid) HIPCHK(c, hipStreamWaitEvent(s, T.used, 0));  // the last frame that read this version is done
+  HIPCHK(c, hipMemcpyAsync(T.d + n * 4 + occ_words * 4, map, 256, hipMemcpyHostToDevice, s));
+  HIPCHK(c, hipEventRecord(T.copied, s));
+  // effective table + occupancy bitmap: bit (t, s) is set when any of the four texels a bilinear lookup with base texel
+  // (s, t) touches has alpha != 0 after the correction.  A clear bit means the lookup returns alpha == 0 EXACTLY (lerps
+  // of zeros), so a kernel may skip the fetch without changing a single bit of the frame.
+  {
+    const int wpr = (sv + 63) / 64;
+    const unsigned blocks = (unsigned)(((size_t)wpr * sg + 3) / 4);
+    hipLaunchKernelGGL(smk_k_tf_effective, dim3(blocks), dim3(256), 0, s, (const uint32_t *)c->d_tf_raw, T.d + n * 4 + occ_words * 4, sv,
+                       sg, roww, (uint32_t *)T.d, (uint32_t *)(T.d + n * 4));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->tf_raw_ev, s));
+    c->tf_raw_ev_valid = true;
+  }
+  // how much of the table is occupied (for the brick flags below): quads whose largest raw alpha maps to non-zero -- the
+  // map is monotone, so that is a threshold on the histogram made when the table was set
   size_t occ_set = 0;
   {
-    uint32_t *occ = reinterpret_cast<uint32_t *>(T.h + n * 4);
-    memset(occ, 0, occ_words * 4);
-    const unsigned char *e = c->h_tf_eff.data();
-    for (int t = 0; t < sg; ++t)
-      for (int sx = 0; sx < sv; ++sx) {
-        const int s1 = std::min(sx + 1, sv - 1), t1 = std::min(t + 1, sg - 1);
-        if (e[((size_t)t * sv + sx) * 4 + 3] | e[((size_t)t * sv + s1) * 4 + 3] | e[((size_t)t1 * sv + sx) * 4 + 3] |
-            e[((size_t)t1 * sv + s1) * 4 + 3])
-          occ[(size_t)t * roww + (sx >> 5)] |= 1u << (sx & 31), ++occ_set;
-      }
+    int a0 = 256;
+    for (int a = 255; a >= 0; --a)
+      if (map[a]) a0 = a;
+      else break;
+    for (int a = a0; a < 256; ++a) occ_set += c->tf_quad_hist[a];
   }
-  if (T.used_valid) HIPCHK(c, hipStreamWaitEvent(s, T.used, 0));  // the last frame that read this version is done
-  HIPCHK(c, hipMemcpyAsync(T.d, T.h, bytes, hipMemcpyHostToDevice, s));
-  HIPCHK(c, hipEventRecord(T.copied, s));
   c->tf_cur = v;
   c->d_tf_vg = reinterpret_cast<uint32_t *>(T.d);
   c->d_tf_occ = reinterpret_cast<uint32_t *>(T.d + n * 4);
-  // this version's brick flags (smk_bricks.hip), behind the copy on the same stream: two small launches per refresh
+  // this version's brick flags (smk_bricks.hip), behind the table on the same stream: two small launches per refresh
   // (a table that is opaque nearly everywhere flags every brick: the flags would only cost their set-up)
   T.bricks_valid = false;
   if (c->opt_bricks && c->d_brick_mm && occ_set * 10 <= n * 9) {
@@ -899,7 +961,12 @@ extern "C" int smk_get_tf2d_effective(smk_ctx *c, unsigned char *out, float *rat
   double inv[16];
   compute_raycoef(c, &rc, inv);
   if (refresh_tf2d(c, rc, c->stream)) return 1;
-  if (out) memcpy(out, c->h_tf_eff.data(), c->h_tf_eff.size());
+  if (out) {  // (the same map applied on the host: this call is for checkers, not for frames)
+    unsigned char map[256];
+    tf2d_alpha_map(c, c->tf_rate_applied, map);
+    memcpy(out, c->h_tf_vg.data(), c->h_tf_vg.size());
+    for (size_t i = 0; i < (size_t)c->sv * c->sg; ++i) out[i * 4 + 3] = map[c->h_tf_vg[i * 4 + 3]];
+  }
   if (rate) *rate = c->tf_rate_applied;
   return 0;
 }

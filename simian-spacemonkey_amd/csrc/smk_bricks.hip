@@ -64,23 +64,30 @@ __global__ __launch_bounds__(256) void smk_k_brick_minmax(const void *vox, int D
   if (lane == 0) mm[brick] = make_float4(vmin, vmax, gmin, gmax);
 }
 
-// sat[(t + 1) * (sv + 1) + (s + 1)] = number of set bits (t', s') with t' <= t, s' <= s; one workgroup
+// sat[(t + 1) * (sv + 1) + (s + 1)] = number of set bits (t', s') with t' <= t, s' <= s; one workgroup, a thread per
+// column: the bits of row t up to column s are popcounts of the row's words (read from an LDS copy of the bitmap when
+// it fits), so a thread's only serial chain is its running sum -- no load depends on a store
 __global__ __launch_bounds__(256) void smk_k_occ_sat(const uint32_t *occ, int roww, int sv, int sg, uint32_t *sat) {
+  extern __shared__ uint32_t bits[];
+  const int words = roww * sg;
+  const bool staged = words <= 12288;
+  if (staged) {
+    for (int i = threadIdx.x; i < words; i += 256) bits[i] = occ[i];
+    __syncthreads();
+  }
+  const uint32_t *src = staged ? bits : occ;
   const int pitch = sv + 1;
   for (int i = threadIdx.x; i < pitch; i += 256) sat[i] = 0;
-  for (int t = threadIdx.x; t < sg; t += 256) {  // rows: prefix over s
-    uint32_t run = 0;
-    sat[(size_t)(t + 1) * pitch] = 0;
-    for (int s = 0; s < sv; ++s) {
-      run += (occ[(size_t)t * roww + (s >> 5)] >> (s & 31)) & 1u;
-      sat[(size_t)(t + 1) * pitch + s + 1] = run;
-    }
-  }
-  __syncthreads();
-  for (int s = threadIdx.x; s < sv; s += 256) {  // columns: prefix over t
+  for (int t = threadIdx.x; t < sg; t += 256) sat[(size_t)(t + 1) * pitch] = 0;
+  for (int s = threadIdx.x; s < sv; s += 256) {
+    const int w = s >> 5;
+    const uint32_t last = 0xffffffffu >> (31 - (s & 31));  // bits 0..s of word w
     uint32_t run = 0;
     for (int t = 0; t < sg; ++t) {
-      run += sat[(size_t)(t + 1) * pitch + s + 1];
+      const uint32_t *row = src + (size_t)t * roww;
+      uint32_t n = __popc(row[w] & last);
+      for (int k = 0; k < w; ++k) n += __popc(row[k]);
+      run += n;
       sat[(size_t)(t + 1) * pitch + s + 1] = run;
     }
   }
@@ -118,7 +125,8 @@ hipError_t smk_bricks_minmax(const void *vox, int dtype, const int D[3], const i
 hipError_t smk_bricks_flags(const float4 *mm, const int nb[3], const uint32_t *occ, int roww, int sv, int sg, uint32_t *sat,
                             unsigned char *flags, hipStream_t s) {
   const long long nbricks = (long long)nb[0] * nb[1] * nb[2];
-  hipLaunchKernelGGL(smk_k_occ_sat, dim3(1), dim3(256), 0, s, occ, roww, sv, sg, sat);
+  const size_t words = (size_t)roww * sg;
+  hipLaunchKernelGGL(smk_k_occ_sat, dim3(1), dim3(256), words <= 12288 ? words * 4 : 0, s, occ, roww, sv, sg, sat);
   hipLaunchKernelGGL(smk_k_brick_flags, dim3((unsigned)((nbricks + 255) / 256)), dim3(256), 0, s, mm, nbricks, sat, sv, sg, flags);
   return hipGetLastError();
 }

@@ -145,7 +145,12 @@ struct smk_ctx {
   int tf_mode = -1;  // 0 1-D, 1 2-D, 2 3-D
   float4 *d_tlut = nullptr;
   int tlut_size = 0;
-  std::vector<unsigned char> h_tf_vg, h_tf_h, h_tf_eff;
+  std::vector<unsigned char> h_tf_vg, h_tf_h;
+  unsigned char *d_tf_raw = nullptr;  // the table as it was set (the effective one = a 256-entry alpha map applied by a kernel)
+  size_t tf_raw_cap = 0;
+  bool tf_raw_stale = true, tf_raw_ev_valid = false;
+  hipEvent_t tf_raw_ev = nullptr;     // the last kernel that read d_tf_raw
+  size_t tf_quad_hist[256] = {0};     // largest raw alpha of each 2 x 2 texel quad, as a histogram
   uint32_t *d_tf_vg = nullptr, *d_tf_h = nullptr, *d_tf3d = nullptr;
   uint32_t *d_tf3d_occ = nullptr;  // occupancy of the dense 3-D table folded over its third axis (smk_set_tf3d)
   int tf3d_occ_roww = 0;
