@@ -62,6 +62,15 @@ extern "C" smk_ctx *smk_create(int device_ordinal, int *err) {
   return c;
 }
 
+static void free_brick_set(BrickSet &B) {
+  if (B.flags) (void)hipFree(B.flags);
+  if (B.sat) (void)hipFree(B.sat);
+  if (B.d_count) (void)hipFree(B.d_count);
+  if (B.h_count) (void)hipHostFree(B.h_count);
+  if (B.counted) (void)hipEventDestroy(B.counted);
+  B = BrickSet();
+}
+
 static void free_volume(smk_ctx *c) {
   if (c->d_vox) (void)hipFree(c->d_vox);
   if (c->d_nrm) (void)hipFree(c->d_nrm);
@@ -82,13 +91,13 @@ extern "C" void smk_destroy(smk_ctx *c) {
   for (smk_ctx::TfVersion &T : c->tfv) {
     if (T.d) (void)hipFree(T.d);
     if (T.h) (void)hipHostFree(T.h);
-    if (T.bricks) (void)hipFree(T.bricks);
-    if (T.sat) (void)hipFree(T.sat);
+    free_brick_set(T.br);
     if (T.copied) (void)hipEventDestroy(T.copied);
     if (T.used) (void)hipEventDestroy(T.used);
   }
   if (c->tf_raw_ev) (void)hipEventDestroy(c->tf_raw_ev);
-  void *ptrs[] = {c->d_tf_raw, c->d_bricks3, c->d_sat3, c->d_tlut, c->d_tf_h, c->d_tf3d, c->d_tf3d_occ, c->d_noise, c->d_out, c->d_depth, c->d_light[0], c->d_light[1]};
+  free_brick_set(c->br3);
+  void *ptrs[] = {c->d_tf_raw, c->d_tlut, c->d_tf_h, c->d_tf3d, c->d_tf3d_occ, c->d_noise, c->d_out, c->d_depth, c->d_light[0], c->d_light[1]};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->slab.h_status) (void)hipHostFree(c->slab.h_status);
@@ -373,15 +382,6 @@ extern "C" int smk_set_tf2d(smk_ctx *c, const unsigned char *deptex, const unsig
   size_t bytes = (size_t)sv * sg * 4;
   c->h_tf_vg.assign(deptex, deptex + bytes);
   c->tf_raw_stale = true;
-  // histogram of the largest alpha of every 2 x 2 texel quad (refresh_tf2d: how much of the table a correction rate leaves occupied)
-  memset(c->tf_quad_hist, 0, sizeof c->tf_quad_hist);
-  for (int t = 0; t < sg; ++t)
-    for (int sx = 0; sx < sv; ++sx) {
-      const int s1 = std::min(sx + 1, sv - 1), t1 = std::min(t + 1, sg - 1);
-      const unsigned char m = std::max(std::max(deptex[((size_t)t * sv + sx) * 4 + 3], deptex[((size_t)t * sv + s1) * 4 + 3]),
-                                       std::max(deptex[((size_t)t1 * sv + sx) * 4 + 3], deptex[((size_t)t1 * sv + s1) * 4 + 3]));
-      ++c->tf_quad_hist[m];
-    }
   if (deptex2) {
     c->h_tf_h.assign(deptex2, deptex2 + bytes);
     if (dev_replace(c, &c->d_tf_h, deptex2, bytes)) return 1;
@@ -805,6 +805,45 @@ static void shading_vectors(const smk_ctx *c, RenderParams &P) {
   }
 }
 
+// brick flags of one table (smk_bricks.hip): buffers sized on demand, the two launches, the count copied back behind them
+static int make_brick_set(smk_ctx *c, BrickSet &B, const uint32_t *occ, int roww, int sv, int sg, hipStream_t s) {
+  const size_t nbricks = (size_t)c->nbr[0] * c->nbr[1] * c->nbr[2], sat_words = (size_t)(sv + 1) * (sg + 1);
+  if (B.flags_cap < nbricks) {  // (a new volume size: rare; hipFree waits for the frames in flight)
+    if (B.flags) (void)hipFree(B.flags);
+    B.flags = nullptr;
+    B.flags_cap = 0;
+    HIPCHK(c, hipMalloc((void **)&B.flags, nbricks));
+    B.flags_cap = nbricks;
+  }
+  if (B.sat_cap < sat_words) {
+    if (B.sat) (void)hipFree(B.sat);
+    B.sat = nullptr;
+    B.sat_cap = 0;
+    HIPCHK(c, hipMalloc((void **)&B.sat, sat_words * 4));
+    B.sat_cap = sat_words;
+  }
+  if (!B.d_count) HIPCHK(c, hipMalloc((void **)&B.d_count, 4));
+  if (!B.h_count) HIPCHK(c, hipHostMalloc((void **)&B.h_count, 4, hipHostMallocDefault));
+  if (!B.counted) HIPCHK(c, hipEventCreateWithFlags(&B.counted, hipEventDisableTiming));
+  else HIPCHK(c, hipEventSynchronize(B.counted));  // (the pinned word's previous copy: long done)
+  HIPCHK(c, smk_bricks_flags(c->d_brick_mm, c->nbr, occ, roww, sv, sg, B.sat, B.flags, B.d_count, s));
+  HIPCHK(c, hipMemcpyAsync(B.h_count, B.d_count, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipEventRecord(B.counted, s));
+  B.valid = true;
+  B.fill = -1.f;
+  return 0;
+}
+
+// the flags a frame should use, or null: none made, or (known by now) nearly every brick is flagged -- a table that
+// leaves nothing to skip would only pay the flags' set-up in every workgroup
+static const unsigned char *brick_flags_to_use(smk_ctx *c, BrickSet &B) {
+  if (!B.valid) return nullptr;
+  if (B.fill < 0.f && hipEventQuery(B.counted) == hipSuccess)
+    B.fill = (float)((double)*B.h_count / ((double)c->nbr[0] * c->nbr[1] * c->nbr[2]));
+  (void)hipGetLastError();
+  return B.fill > 0.9f ? nullptr : B.flags;
+}
+
 // NV20VolRen3D::copyScale (:1645-1660) with the rate the renderer would pass (:94-98, :117)
 // The effective (V,G) table of a frame: opacity correction as copyScale does it, plus the occupancy bitmap.  In steps
 // mode the correction rate follows the view-depth extent, i.e. it changes with every camera move: the table is then
@@ -913,41 +952,12 @@ static int refresh_tf2d(smk_ctx *c, const smk_raycoef &rc, hipStream_t s) {
     HIPCHK(c, hipEventRecord(c->tf_raw_ev, s));
     c->tf_raw_ev_valid = true;
   }
-  // how much of the table is occupied (for the brick flags below): quads whose largest raw alpha maps to non-zero -- the
-  // map is monotone, so that is a threshold on the histogram made when the table was set
-  size_t occ_set = 0;
-  {
-    int a0 = 256;
-    for (int a = 255; a >= 0; --a)
-      if (map[a]) a0 = a;
-      else break;
-    for (int a = a0; a < 256; ++a) occ_set += c->tf_quad_hist[a];
-  }
   c->tf_cur = v;
   c->d_tf_vg = reinterpret_cast<uint32_t *>(T.d);
   c->d_tf_occ = reinterpret_cast<uint32_t *>(T.d + n * 4);
   // this version's brick flags (smk_bricks.hip), behind the table on the same stream: two small launches per refresh
-  // (a table that is opaque nearly everywhere flags every brick: the flags would only cost their set-up)
-  T.bricks_valid = false;
-  if (c->opt_bricks && c->d_brick_mm && occ_set * 10 <= n * 9) {
-    T.bricks_valid = true;
-    const size_t nbricks = (size_t)c->nbr[0] * c->nbr[1] * c->nbr[2], sat_words = (size_t)(sv + 1) * (sg + 1);
-    if (T.bricks_cap < nbricks) {  // (a new volume size: rare; hipFree waits for the frames in flight)
-      if (T.bricks) (void)hipFree(T.bricks);
-      T.bricks = nullptr;
-      T.bricks_cap = 0;
-      HIPCHK(c, hipMalloc((void **)&T.bricks, nbricks));
-      T.bricks_cap = nbricks;
-    }
-    if (T.sat_cap < sat_words) {
-      if (T.sat) (void)hipFree(T.sat);
-      T.sat = nullptr;
-      T.sat_cap = 0;
-      HIPCHK(c, hipMalloc((void **)&T.sat, sat_words * 4));
-      T.sat_cap = sat_words;
-    }
-    HIPCHK(c, smk_bricks_flags(c->d_brick_mm, c->nbr, c->d_tf_occ, roww, sv, sg, T.sat, T.bricks, s));
-  }
+  T.br.valid = false;
+  if (c->opt_bricks && c->d_brick_mm && make_brick_set(c, T.br, c->d_tf_occ, roww, sv, sg, s)) return 1;
   c->tf_occ_roww = roww;
   c->tf_rate_applied = sr;
   c->tf_dirty = false;
@@ -1251,20 +1261,14 @@ static int build_params(smk_ctx *c, RenderParams &P, hipStream_t s) {
   P.bricks = nullptr;
   for (int a = 0; a < 3; ++a) P.nbr[a] = c->nbr[a];
   if (c->opt_bricks && c->d_brick_mm) {
-    if (c->tf_mode == 1 && c->tf_cur >= 0 && c->tfv[c->tf_cur].bricks_valid) P.bricks = c->tfv[c->tf_cur].bricks;
+    if (c->tf_mode == 1 && c->tf_cur >= 0) P.bricks = brick_flags_to_use(c, c->tfv[c->tf_cur].br);
     if (c->tf_mode == 2 && c->d_tf3d_occ) {
-      if (c->bricks3_dirty || !c->d_bricks3) {
+      if (c->bricks3_dirty || !c->br3.valid) {
         HIPCHK(c, hipDeviceSynchronize());  // (a new table or volume: rare; frames in flight may still read the old flags)
-        if (c->d_bricks3) (void)hipFree(c->d_bricks3);
-        if (c->d_sat3) (void)hipFree(c->d_sat3);
-        c->d_bricks3 = nullptr;
-        c->d_sat3 = nullptr;
-        HIPCHK(c, hipMalloc((void **)&c->d_bricks3, (size_t)c->nbr[0] * c->nbr[1] * c->nbr[2]));
-        HIPCHK(c, hipMalloc((void **)&c->d_sat3, (size_t)(c->s3v + 1) * (c->s3g + 1) * 4));
-        HIPCHK(c, smk_bricks_flags(c->d_brick_mm, c->nbr, c->d_tf3d_occ, c->tf3d_occ_roww, c->s3v, c->s3g, c->d_sat3, c->d_bricks3, s));
+        if (make_brick_set(c, c->br3, c->d_tf3d_occ, c->tf3d_occ_roww, c->s3v, c->s3g, s)) return 1;
         c->bricks3_dirty = false;
       }
-      P.bricks = c->d_bricks3;
+      P.bricks = brick_flags_to_use(c, c->br3);
     }
   }
   P.W = c->W;

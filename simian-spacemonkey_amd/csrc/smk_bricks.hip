@@ -94,9 +94,10 @@ __global__ __launch_bounds__(256) void smk_k_occ_sat(const uint32_t *occ, int ro
 }
 
 __global__ __launch_bounds__(256) void smk_k_brick_flags(const float4 *mm, long long nbricks, const uint32_t *sat, int sv, int sg,
-                                                          unsigned char *flags) {
+                                                          unsigned char *flags, unsigned *count) {
   const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (b >= nbricks) return;
+  bool set = false;
+  if (b < nbricks) {
   const float4 r = mm[b];
   // base texel of a channel value c: floor(clamp(c * size - 0.5, 0, size - 1)), at most size - 2 (smk_lin_clamp)
   auto base = [](float c, int size) -> int {
@@ -109,7 +110,12 @@ __global__ __launch_bounds__(256) void smk_k_brick_flags(const float4 *mm, long 
   const uint32_t n = sat[(size_t)(t_hi + 1) * pitch + s_hi + 1] - sat[(size_t)t_lo * pitch + s_hi + 1] -
                      sat[(size_t)(t_hi + 1) * pitch + s_lo] + sat[(size_t)t_lo * pitch + s_lo];
   // (NaN data compares false everywhere above and ends with the full range: flagged)
-  flags[b] = (n != 0 || !(r.x <= r.y) || !(r.z <= r.w)) ? 1 : 0;
+  set = n != 0 || !(r.x <= r.y) || !(r.z <= r.w);
+  flags[b] = set ? 1 : 0;
+  }
+  // how many bricks are flagged: when nearly all are, the flags only cost their set-up and the caller drops them
+  const unsigned long long m = __ballot(set);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned)__popcll(m));
 }
 
 }  // namespace
@@ -123,10 +129,12 @@ hipError_t smk_bricks_minmax(const void *vox, int dtype, const int D[3], const i
 }
 
 hipError_t smk_bricks_flags(const float4 *mm, const int nb[3], const uint32_t *occ, int roww, int sv, int sg, uint32_t *sat,
-                            unsigned char *flags, hipStream_t s) {
+                            unsigned char *flags, unsigned *count, hipStream_t s) {
   const long long nbricks = (long long)nb[0] * nb[1] * nb[2];
   const size_t words = (size_t)roww * sg;
   hipLaunchKernelGGL(smk_k_occ_sat, dim3(1), dim3(256), words <= 12288 ? words * 4 : 0, s, occ, roww, sv, sg, sat);
-  hipLaunchKernelGGL(smk_k_brick_flags, dim3((unsigned)((nbricks + 255) / 256)), dim3(256), 0, s, mm, nbricks, sat, sv, sg, flags);
+  hipError_t e = hipMemsetAsync(count, 0, 4, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(smk_k_brick_flags, dim3((unsigned)((nbricks + 255) / 256)), dim3(256), 0, s, mm, nbricks, sat, sv, sg, flags, count);
   return hipGetLastError();
 }

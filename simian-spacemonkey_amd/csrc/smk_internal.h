@@ -104,6 +104,17 @@ struct SlabAux {
   int trace_cap = 0, trace_n = 0;
 };
 
+// the flags of one table (version): buffers, and how many bricks came out flagged (copied back behind the kernel)
+struct BrickSet {
+  unsigned char *flags = nullptr;
+  uint32_t *sat = nullptr;
+  unsigned *d_count = nullptr, *h_count = nullptr;  // device word; pinned copy
+  hipEvent_t counted = nullptr;
+  size_t flags_cap = 0, sat_cap = 0;
+  bool valid = false;
+  float fill = -1.f;  // share of the bricks that are flagged; < 0: not known yet
+};
+
 struct smk_ctx {
   int device = 0;
   std::string err;
@@ -130,8 +141,7 @@ struct smk_ctx {
   void *d_vox_x = nullptr;  // x-major copy [x][z][y] for views whose principal axis is x (lazy)
   float4 *d_brick_mm = nullptr;  // per brick of the stored box: range of the first two channels (smk_bricks.hip)
   int nbr[3] = {0, 0, 0};
-  unsigned char *d_bricks3 = nullptr;  // brick flags under the dense 3-D table (the 2-D table's live in its versions)
-  uint32_t *d_sat3 = nullptr;
+  BrickSet br3;                        // brick flags under the dense 3-D table (the 2-D table's live in its versions)
   bool bricks3_dirty = true;
   std::string slab_why;     // why the last frame fell back to the gather kernel ("" if it did not)
   uint32_t *d_nrm = nullptr;
@@ -150,7 +160,6 @@ struct smk_ctx {
   size_t tf_raw_cap = 0;
   bool tf_raw_stale = true, tf_raw_ev_valid = false;
   hipEvent_t tf_raw_ev = nullptr;     // the last kernel that read d_tf_raw
-  size_t tf_quad_hist[256] = {0};     // largest raw alpha of each 2 x 2 texel quad, as a histogram
   uint32_t *d_tf_vg = nullptr, *d_tf_h = nullptr, *d_tf3d = nullptr;
   uint32_t *d_tf3d_occ = nullptr;  // occupancy of the dense 3-D table folded over its third axis (smk_set_tf3d)
   int tf3d_occ_roww = 0;
@@ -160,10 +169,7 @@ struct smk_ctx {
   // stalling the frames in flight when the correction rate moves with the camera (smk_api.hip refresh_tf2d)
   struct TfVersion {
     unsigned char *d = nullptr, *h = nullptr;  // device copy; pinned staging
-    unsigned char *bricks = nullptr;            // this version's brick flags (smk_bricks.hip) + the summed-area table they
-    uint32_t *sat = nullptr;                    // were made from; sized for the volume / the table when first needed
-    size_t bricks_cap = 0, sat_cap = 0;
-    bool bricks_valid = false;                  // (not made for a table that is opaque nearly everywhere)
+    BrickSet br;                                // this version's brick flags (smk_bricks.hip)
     size_t cap = 0;
     hipEvent_t copied = nullptr, used = nullptr;
     bool used_valid = false;
@@ -235,7 +241,7 @@ struct smk_ctx {
 // brick flags (smk_bricks.hip)
 hipError_t smk_bricks_minmax(const void *vox, int dtype, const int D[3], const int nb[3], float4 *mm, hipStream_t s);
 hipError_t smk_bricks_flags(const float4 *mm, const int nb[3], const uint32_t *occ, int roww, int sv, int sg, uint32_t *sat,
-                            unsigned char *flags, hipStream_t s);
+                            unsigned char *flags, unsigned *count, hipStream_t s);
 
 // launchers (one translation unit per kernel family)
 hipError_t smk_launch_gather(const RenderParams &P, int dtype, int tf_mode, int shade_kind,

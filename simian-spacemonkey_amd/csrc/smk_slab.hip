@@ -236,7 +236,9 @@ __device__ __forceinline__ float slab_tex_chan(const SlabTexel4 &x, int k) {
 // (2 x 9 waves = 5 on one SIMD) if the kernel stays within 96 VGPRs
 // TF: 1 = 2-D (V,G) table x optional third-axis alpha (NV20VolRen3D.cpp:544-596), 2 = dense 3-D (v,g,h)
 // table (TFWidgetRen.cpp:779-845; BASELINE configs 4/5)
-template <int DT, int SH, int PERM, int NW, int NL, bool DIAG, int TF = 1>
+// (BR: the instance knows about brick flags -- EMPTY LAYERS; frames without flags run instances that carry none of it:
+//  the run-time test alone, three per loop turn, cost them 12 % in scalar registers spilled)
+template <int DT, int SH, int PERM, int NW, int NL, bool DIAG, int TF = 1, bool BR = true>
 #ifndef SLAB_BIG_WAVES
 #define SLAB_BIG_WAVES 12  // workgroups of more waves than this are "big": one per CU
 #endif
@@ -291,6 +293,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 
   const int tile = Q.order[blockIdx.x];
   if (tile < 0) return;  // whole workgroup leaves together
+  const bool flags = BR && Q.bricks != nullptr;
   const bool tracing = DIAG && Q.trace != nullptr && (P.lockstep & 32);  // (diagnostic: workgroup timeline)
   // the workgroup's duration feeds the next frame's schedule (see smk_launch_slab): one scalar
   // timestamp at each end and one 4-byte store per tile
@@ -508,7 +511,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   // the tile's range = "the rest"); rays and loaders step over such a run at once (see there).
   // Three steps, a barrier between them; the flags are read from memory once per layer of BRICKS, a lane per brick:
   // (the first version read them per slice and thread, one after the other: 40 us per workgroup, a fifth of the frame)
-  if (Q.bricks != nullptr && npos > 0) {
+  if (flags && npos > 0) {
     constexpr int BL = SMK_BRICK_LOG2;
     __syncthreads();
     auto extent = [&](int e, int &ulo, int &uhi, int &vlo, int &vhi) {
@@ -747,7 +750,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           // goes slice by slice below.
           // (slice q + k lies between the layers of positions q + k - 1 and q + k when the march goes up the slice index,
           //  q + k and q + k + 1 when it goes down: there the last slice of the run borders the layer behind it)
-          int run = Q.bricks != nullptr ? __builtin_amdgcn_readlane(ent_run, q & 63) : 0;
+          int run = flags ? __builtin_amdgcn_readlane(ent_run, q & 63) : 0;
           if (dir < 0 && run > 1) --run;
           run = min(run, npos + 1 - q);
           if (run > 0 && (inflight == 0 || run >= 8)) {
@@ -1047,17 +1050,17 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           // the position arithmetic below covers the LDS round trip
           const int *te = reinterpret_cast<const int *>(smem + (wtab_addr - ring_addr)) + 2 * (__mul24(psgn, pb) + eoff);  // (24-bit multiply: full rate; |pb| < 4096 on a lane that works)
           base_a = te[0];
-          base_b = te[2] & ~1;  // (bit 0: the NEXT layer's flag)
+          base_b = BR ? (te[2] & ~1) : te[2];  // (bit 0: the NEXT layer's flag)
         }
         // EMPTY LAYERS: nothing in this sample's layer can be visible for any ray of the tile -- the sample is exactly
         // transparent, and its slices may not even have been streamed
-        if (Q.bricks != nullptr) work = work && !(base_a & 1);
+        if (flags) work = work && !(base_a & 1);
         // the plane of this ray's next sample: the next one, or -- from a layer that starts a run of empty ones (the
         // entry holds its length, see the set-up) -- the first plane whose base slice lies behind the run.  The planes
         // in between fall into empty layers, all of them: positions are monotone in the plane index.
         int m_next = m + 1;
 #ifndef SLAB_NO_JUMP
-        if (Q.bricks != nullptr && act && (base_a & 3) == 3) {
+        if (flags && act && (base_a & 3) == 3) {
           const int ptar = pb + (base_a >> 2);  // first position behind the run
           if (ptar >= npos) m_next = m1 + 1;    // nothing but empty layers to the end of the tile's range
           else {
@@ -1088,7 +1091,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
           else { z0 = car_i; fz = car_sc - (float)car_i; }
           (void)x1; (void)y1; (void)z1;
           const int iu = AU == 0 ? x0 : y0, iv = AV == 1 ? y0 : z0;  // global voxel indices
-          if (count && Q.bricks != nullptr)  // (diagnostic: would this lane's OWN brick have let it skip the sample?)
+          if (count && flags)  // (diagnostic: would this lane's OWN brick have let it skip the sample?)
             d_own = Q.bricks[(size_t)((car_i - Q.Os) >> SMK_BRICK_LOG2) * Q.bss + (size_t)((iv - Q.Ov) >> SMK_BRICK_LOG2) * Q.bsv +
                              (size_t)((iu - Q.Ou) >> SMK_BRICK_LOG2) * Q.bsu] != 0;
           const unsigned lo_off = __umul24((unsigned)iv, pitch_b) + ((unsigned)iu << VBL);  // (24-bit multiply: full rate)
@@ -1560,9 +1563,9 @@ bool slab_bundle_slice_range_exact(const RenderParams &P, double fx0, double fy0
 }
 }  // namespace
 
-template <int DT, int SH, int PERM, int NW, int NL, bool DIAG, int TF = 1>
+template <int DT, int SH, int PERM, int NW, int NL, bool DIAG, int TF = 1, bool BR = true>
 static hipError_t launch_slab(const RenderParams &P, const SlabParams &Q, size_t lds, int nblocks, hipStream_t s) {
-  auto k = smk_k_slab<DT, SH, PERM, NW, NL, DIAG, TF>;
+  auto k = smk_k_slab<DT, SH, PERM, NW, NL, DIAG, TF, BR>;
   static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -1928,9 +1931,16 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
         aux->ticks_pending = false;
       }
       (void)hipGetLastError();
-      if (aux->ticks_good_sig == tsig && (int)aux->ticks_good.size() == nt)
-        for (int t = 0; t < nt; ++t)
-          if (aux->ticks_good[t] > 0) work[t] = (int)std::min<unsigned>(aux->ticks_good[t], 1u << 30);
+      if (aux->ticks_good_sig == tsig && (int)aux->ticks_good.size() == nt) {
+        // (not when every workgroup is over in a few tens of microseconds -- an opaque table: such durations are mostly
+        //  dispatch noise, and a schedule balanced on noise gives the XCDs unequal numbers of equal tiles: the same frame
+        //  then takes 0.11 or 0.20 ms from one re-plan to the next)
+        unsigned longest_ticks = 0;
+        for (int t = 0; t < nt; ++t) longest_ticks = std::max(longest_ticks, aux->ticks_good[t]);
+        if (longest_ticks >= 10000u)  // 100 us at 100 MHz
+          for (int t = 0; t < nt; ++t)
+            if (aux->ticks_good[t] > 0) work[t] = (int)std::min<unsigned>(aux->ticks_good[t], 1u << 30);
+      }
       if (nt > aux->ticks_cap) {
         if (aux->ticks_pending) (void)hipEventSynchronize(aux->ticks_ev);
         aux->ticks_pending = false;
@@ -2115,21 +2125,24 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
 #define GO(D, S, R, N, L)                                                                              \
   if (dtype == D && shade_kind == S && Q.perm == R && nw == N && nl == L) {                          \
     if (tf_mode == 2) {                                                                              \
-      if constexpr ((N == 8 && L == 2) || (N == 10 && L == 2) || (N == 12 && L == 4))                \
-        return after_launch(launch_slab<D, S, R, N, L, false, 2>(P, Q, lds, nblocks, s));            \
+      if constexpr ((N == 8 && L == 2) || (N == 10 && L == 2) || (N == 12 && L == 4)) {              \
+        if (Q.bricks) return after_launch(launch_slab<D, S, R, N, L, false, 2, true>(P, Q, lds, nblocks, s));  \
+        return after_launch(launch_slab<D, S, R, N, L, false, 2, false>(P, Q, lds, nblocks, s));     \
+      }                                                                                              \
       *why = "no dense-3-D-table instance for this tile size";                                       \
       return hipErrorNotSupported;                                                                   \
     }                                                                                                \
     if (tf_mode == 0) {                                                                              \
       if constexpr (S == 0 && ((N == 8 && L == 2) || (N == 10 && L == 2) || (N == 12 && L == 4)))    \
-        return after_launch(launch_slab<D, S, R, N, L, false, 0>(P, Q, lds, nblocks, s));            \
+        return after_launch(launch_slab<D, S, R, N, L, false, 0, false>(P, Q, lds, nblocks, s));     \
       *why = "no colour-table instance for this tile size";                                          \
       return hipErrorNotSupported;                                                                   \
     }                                                                                                \
     if constexpr (D == 1 && S == 1) {                                                                \
       if (diag) return after_launch(launch_slab<D, S, R, N, L, true>(P, Q, lds, nblocks, s));        \
     }                                                                                                \
-    return after_launch(launch_slab<D, S, R, N, L, false>(P, Q, lds, nblocks, s));                   \
+    if (Q.bricks) return after_launch(launch_slab<D, S, R, N, L, false, 1, true>(P, Q, lds, nblocks, s));  \
+    return after_launch(launch_slab<D, S, R, N, L, false, 1, false>(P, Q, lds, nblocks, s));         \
   }
   // product tile shapes: 32x16 px with 8+2 waves, 32x24 px with 12+4; the others are experiment knobs (option "tile")
 #ifdef SLAB_ALL_TILES
