@@ -1921,8 +1921,14 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
             aux->ticks_good.assign(aux->h_ticks, aux->h_ticks + aux->ticks_pending_n);
             aux->ticks_adopted = 0;
           } else {
-            for (int t = 0; t < aux->ticks_pending_n; ++t)  // damped: half the old weight, half the new measurement
-              aux->ticks_good[t] = (aux->ticks_good[t] + aux->h_ticks[t] + 1) / 2;
+            // damped: half the old weight, half the new measurement.  (Workgroups of a few tens of microseconds -- an
+            // opaque table -- measure mostly who ran beside them: averaged, the schedule oscillated between two plans,
+            // 0.11 and 0.20 ms for the same frame; there the SHORTEST duration seen is the tile's own cost.)
+            unsigned longest_new = 0;
+            for (int t = 0; t < aux->ticks_pending_n; ++t) longest_new = std::max(longest_new, aux->h_ticks[t]);
+            for (int t = 0; t < aux->ticks_pending_n; ++t)
+              aux->ticks_good[t] = longest_new < 10000u ? (aux->h_ticks[t] ? std::min(std::max(aux->ticks_good[t], 1u), aux->h_ticks[t]) : aux->ticks_good[t])
+                                                        : (aux->ticks_good[t] + aux->h_ticks[t] + 1) / 2;
             ++aux->ticks_adopted;
           }
           aux->ticks_good_sig = aux->ticks_pending_sig;
@@ -1932,14 +1938,8 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
       }
       (void)hipGetLastError();
       if (aux->ticks_good_sig == tsig && (int)aux->ticks_good.size() == nt) {
-        // (not when every workgroup is over in a few tens of microseconds -- an opaque table: such durations are mostly
-        //  dispatch noise, and a schedule balanced on noise gives the XCDs unequal numbers of equal tiles: the same frame
-        //  then takes 0.11 or 0.20 ms from one re-plan to the next)
-        unsigned longest_ticks = 0;
-        for (int t = 0; t < nt; ++t) longest_ticks = std::max(longest_ticks, aux->ticks_good[t]);
-        if (longest_ticks >= 10000u)  // 100 us at 100 MHz
-          for (int t = 0; t < nt; ++t)
-            if (aux->ticks_good[t] > 0) work[t] = (int)std::min<unsigned>(aux->ticks_good[t], 1u << 30);
+        for (int t = 0; t < nt; ++t)
+          if (aux->ticks_good[t] > 0) work[t] = (int)std::min<unsigned>(aux->ticks_good[t], 1u << 30);
       }
       if (nt > aux->ticks_cap) {
         if (aux->ticks_pending) (void)hipEventSynchronize(aux->ticks_ev);
