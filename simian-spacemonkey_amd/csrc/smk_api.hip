@@ -64,6 +64,7 @@ extern "C" smk_ctx *smk_create(int device_ordinal, int *err) {
 
 static void free_brick_set(BrickSet &B) {
   if (B.flags) (void)hipFree(B.flags);
+  if (B.dil) (void)hipFree(B.dil);
   if (B.sat) (void)hipFree(B.sat);
   if (B.d_count) (void)hipFree(B.d_count);
   if (B.h_count) (void)hipHostFree(B.h_count);
@@ -831,6 +832,7 @@ static int make_brick_set(smk_ctx *c, BrickSet &B, const uint32_t *occ, int roww
   HIPCHK(c, hipEventRecord(B.counted, s));
   B.valid = true;
   B.fill = -1.f;
+  B.dil_r[0] = -1;  // (the dilated copy belongs to the old flags)
   return 0;
 }
 
@@ -1260,8 +1262,13 @@ static int build_params(smk_ctx *c, RenderParams &P, hipStream_t s) {
   // brick flags (smk_bricks.hip): the 2-D table's come with its version; the dense 3-D table's are made here when stale
   P.bricks = nullptr;
   for (int a = 0; a < 3; ++a) P.nbr[a] = c->nbr[a];
+  BrickSet *bset = nullptr;
+  P.bricks_dil = nullptr;
   if (c->opt_bricks && c->d_brick_mm) {
-    if (c->tf_mode == 1 && c->tf_cur >= 0) P.bricks = brick_flags_to_use(c, c->tfv[c->tf_cur].br);
+    if (c->tf_mode == 1 && c->tf_cur >= 0) {
+      P.bricks = brick_flags_to_use(c, c->tfv[c->tf_cur].br);
+      bset = &c->tfv[c->tf_cur].br;
+    }
     if (c->tf_mode == 2 && c->d_tf3d_occ) {
       if (c->bricks3_dirty || !c->br3.valid) {
         HIPCHK(c, hipDeviceSynchronize());  // (a new table or volume: rare; frames in flight may still read the old flags)
@@ -1269,6 +1276,7 @@ static int build_params(smk_ctx *c, RenderParams &P, hipStream_t s) {
         c->bricks3_dirty = false;
       }
       P.bricks = brick_flags_to_use(c, c->br3);
+      bset = &c->br3;
     }
   }
   P.W = c->W;
@@ -1292,6 +1300,33 @@ static int build_params(smk_ctx *c, RenderParams &P, hipStream_t s) {
       int need = 1 + (int)ceil(0.5 * (fabs(c->pw[0]) + fabs(c->pw[1])) * c->N[a]);
       if (c->halo < need && c->D[a] < c->N[a])
         FAIL(c, "smk_render: perturbation needs halo >= %d voxels on a sharded volume (have %d); set option 'halo' before upload", need, c->halo);
+    }
+  }
+  // a perturbed fetch lands within 0.5 (|w0| + |w1|) N voxels of the undisplaced position on every axis: when that is a
+  // brick or two, flags spread that far tell BEFORE the noise lookups that nothing visible can be reached
+  if (P.pert_on && P.bricks && bset) {
+    int r[3];
+    bool near = true;
+    for (int a = 0; a < 3; ++a) {
+      const int dv = (int)ceil(0.5 * (fabs(c->pw[0]) + fabs(c->pw[1])) * c->N[a] + 1e-3);
+      r[a] = (dv + (1 << SMK_BRICK_LOG2) - 1) >> SMK_BRICK_LOG2;
+      near = near && r[a] <= 2;
+    }
+    if (near) {
+      const size_t nbricks = (size_t)c->nbr[0] * c->nbr[1] * c->nbr[2];
+      if (bset->dil_cap < nbricks) {
+        if (bset->dil) (void)hipFree(bset->dil);
+        bset->dil = nullptr;
+        bset->dil_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&bset->dil, nbricks));
+        bset->dil_cap = nbricks;
+        bset->dil_r[0] = -1;
+      }
+      if (bset->dil_r[0] != r[0] || bset->dil_r[1] != r[1] || bset->dil_r[2] != r[2]) {
+        HIPCHK(c, smk_bricks_dilate(bset->flags, c->nbr, r, bset->dil, s));
+        for (int a = 0; a < 3; ++a) bset->dil_r[a] = r[a];
+      }
+      P.bricks_dil = bset->dil;
     }
   }
   P.wave_w = c->opt_wave_w;

@@ -118,7 +118,26 @@ __global__ __launch_bounds__(256) void smk_k_brick_flags(const float4 *mm, long 
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned)__popcll(m));
 }
 
+// out[b] = any flag within (rx, ry, rz) bricks of b: where a perturbed fetch (displaced by at most that far) can land
+__global__ __launch_bounds__(256) void smk_k_brick_dilate(const unsigned char *flags, int nbx, int nby, int nbz, int rx, int ry, int rz,
+                                                           unsigned char *out) {
+  const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (b >= (long long)nbx * nby * nbz) return;
+  const int bx = (int)(b % nbx), by = (int)((b / nbx) % nby), bz = (int)(b / ((long long)nbx * nby));
+  unsigned any = 0;
+  for (int z = max(bz - rz, 0); z <= min(bz + rz, nbz - 1); ++z)
+    for (int y = max(by - ry, 0); y <= min(by + ry, nby - 1); ++y)
+      for (int x = max(bx - rx, 0); x <= min(bx + rx, nbx - 1); ++x) any |= flags[((size_t)z * nby + y) * nbx + x];
+  out[b] = any ? 1 : 0;
+}
+
 }  // namespace
+
+hipError_t smk_bricks_dilate(const unsigned char *flags, const int nb[3], const int r[3], unsigned char *out, hipStream_t s) {
+  const long long nbricks = (long long)nb[0] * nb[1] * nb[2];
+  hipLaunchKernelGGL(smk_k_brick_dilate, dim3((unsigned)((nbricks + 255) / 256)), dim3(256), 0, s, flags, nb[0], nb[1], nb[2], r[0], r[1], r[2], out);
+  return hipGetLastError();
+}
 
 hipError_t smk_bricks_minmax(const void *vox, int dtype, const int D[3], const int nb[3], float4 *mm, hipStream_t s) {
   const long long nbricks = (long long)nb[0] * nb[1] * nb[2];

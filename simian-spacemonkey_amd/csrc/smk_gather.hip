@@ -87,6 +87,20 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
     if (P.cplane_on && !(__fmaf_rn(p0, P.cplane[0], __fmaf_rn(p1, P.cplane[1], __fmaf_rn(p2, P.cplane[2], P.cplane[3]))) >= 0.0f)) continue;
 
     if (P.pert_on) {
+      if (TF != 0 && P.bricks_dil != nullptr) {
+        // every brick the displaced fetch can reach from here is flagged empty (smk_api.hip build_params): the sample is
+        // exactly transparent wherever the noise sends it -- neither the noise nor the voxels are looked at
+        int u0, u1, v0, v1, w0, w1;
+        float fu, fv, fw;
+        smk_lin_clamp(p0, P.N[0], u0, u1, fu);
+        smk_lin_clamp(p1, P.N[1], v0, v1, fv);
+        smk_lin_clamp(p2, P.N[2], w0, w1, fw);
+        u0 = min(max(u0 - P.O[0], 0), P.D[0] - 1);
+        v0 = min(max(v0 - P.O[1], 0), P.D[1] - 1);
+        w0 = min(max(w0 - P.O[2], 0), P.D[2] - 1);
+        if (!P.bricks_dil[((size_t)(w0 >> SMK_BRICK_LOG2) * P.nbr[1] + (size_t)(v0 >> SMK_BRICK_LOG2)) * P.nbr[0] + (size_t)(u0 >> SMK_BRICK_LOG2)])
+          continue;
+      }
       // tc' = tc + sum w_m (noise(tc s_m) - .5)   (R8kVolRen3D_cpy.cpp:1590-1595, 3462-3490)
       float t0 = (p0 + 0.5f) * P.invN[0], t1 = (p1 + 0.5f) * P.invN[1], t2 = (p2 + 0.5f) * P.invN[2];
       float o0 = 0.f, o1 = 0.f, o2 = 0.f;

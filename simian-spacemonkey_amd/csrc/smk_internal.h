@@ -47,6 +47,7 @@ struct RenderParams {
   // the brick can be visible under the current table; null = not available (1-D colour table, option "bricks" 0)
   const unsigned char *bricks;
   int nbr[3];
+  const unsigned char *bricks_dil;  // the same, each flag spread over the bricks a perturbed fetch can reach from there, or null
   // ---- camera / sample placement
   smk_raycoef rc;
   int W, H;
@@ -104,6 +105,7 @@ struct SlabAux {
   int trace_cap = 0, trace_n = 0;
 };
 
+hipError_t smk_bricks_dilate(const unsigned char *flags, const int nb[3], const int r[3], unsigned char *out, hipStream_t s);
 // the flags of one table (version): buffers, and how many bricks came out flagged (copied back behind the kernel)
 struct BrickSet {
   unsigned char *flags = nullptr;
@@ -111,6 +113,9 @@ struct BrickSet {
   unsigned *d_count = nullptr, *h_count = nullptr;  // device word; pinned copy
   hipEvent_t counted = nullptr;
   size_t flags_cap = 0, sat_cap = 0;
+  unsigned char *dil = nullptr;  // flags dilated by dil_r bricks per axis (perturbed fetch), made on demand
+  size_t dil_cap = 0;
+  int dil_r[3] = {-1, -1, -1};
   bool valid = false;
   float fill = -1.f;  // share of the bricks that are flagged; < 0: not known yet
 };

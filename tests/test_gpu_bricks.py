@@ -156,3 +156,27 @@ def test_shadow_frames(R, f32):
     sc.shadow = None
     push_scene(R, sc)
     R.set_option("bricks", 1)
+
+
+@pytest.mark.parametrize("weights", [(.2, .1, 0, 0), (.05, .02, 0, 0), (.6, .3, 0, 0)])
+@pytest.mark.parametrize("kind", ["cfg3", "tf3d_panes"])
+def test_perturbed_fetch(R, kind, weights):
+    """a noise-displaced fetch lands within 0.5 (|w0| + |w1|) N voxels of where it started: the flags, spread over the
+    bricks within that reach, stop a sample before its noise lookups (reach of one or two bricks; beyond that the
+    sample's own displaced brick is still tested) -- frames equal with the flags on and off, and the checker agrees"""
+    sc = make_scene(kind, n=64, size=96, steps=128, pose="rot", f32=True, shade=1, pert=True)
+    sc.pert_w = weights
+    ref = sc.render()
+    out = {}
+    for b in (0, 1):
+        R.set_option("bricks", b)
+        push_scene(R, sc)
+        R.set_option("kernel", 0)
+        out[b] = R.render()
+        assert R.last_frame_info()[0] == 1
+    assert np.array_equal(out[0], out[1])
+    assert np.abs(out[1] - ref).max() <= TOL
+    assert out[1][..., 3].max() > 0.05
+    sc.noise = None
+    push_scene(R, sc)
+    R.set_option("bricks", 1)
