@@ -19,7 +19,9 @@ def gpu_only(R, sc, tag):
     """the two kernels against each other only (large cases: no CPU frame)"""
     push_scene(R, sc)
     R.set_option("kernel", 1)
+    R.set_option("bricks", 0)      # the reference frame: gather kernel, every sample fetched and classified
     a = R.render()
+    R.set_option("bricks", 1)
     R.set_option("kernel", 2)
     try:
         b = R.render()

@@ -39,9 +39,11 @@ def main():
             k = r.last_frame_info()[0]
             by_kernel[k] = by_kernel.get(k, 0) + 1
             r.set_option("kernel", 1)
+            r.set_option("bricks", 0)      # the reference frame: gather kernel, every sample fetched and classified
             r.render_device(b.data_ptr(), None, st)
             torch.cuda.synchronize()
             r.set_option("kernel", 0)
+            r.set_option("bricks", 1)
             if not torch.equal(a, b):
                 bad += 1
                 print("frame %d (kernel %d): differs from the gather kernel by %g" % (f, k, float((a - b).abs().max())), flush=True)
