@@ -195,7 +195,8 @@ def run_frames(r, nframes, frame, world, pipeline):
         pipeline[0].drain()
 
 
-SETTLE_FRAMES = 6   # untimed set-up before the warm-up: auto mode times both ray-marchers (4 frames)
+SETTLE_FRAMES = 24  # untimed set-up before the warm-up: auto mode times both ray-marchers (4 frames), and the tile schedule
+                    # adopts the workgroups' measured durations at once, then after 4, 8 and 16 frames (steady state from there)
 #                     and the tile schedule takes its weights from a measured frame
 
 
