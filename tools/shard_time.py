@@ -26,5 +26,6 @@ for nranks in (1, 2, 4, 8):
         torch.cuda.synchronize()
         t = (time.perf_counter() - t0) / K * 1e3
         kms, kn = r.timing_read()
-        print("nranks %d rank %d: %.3f ms/frame wall, kernel %.3f ms, kernel id %d" % (nranks, rank, t, kms, r.last_frame_info()[0]), flush=True)
+        print("nranks %d rank %d: %.3f ms/frame wall, kernel %.3f ms, kernel id %d; workgroups: longest %.3f ms, sum %.1f ms; slices streamed %.3f" %
+              (nranks, rank, t, kms, r.last_frame_info()[0], r.stat("slab_tile_ms_max"), r.stat("slab_tile_ms_sum"), r.stat("slab_streamed_fraction")), flush=True)
         r.close()
