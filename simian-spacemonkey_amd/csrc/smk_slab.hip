@@ -1387,6 +1387,12 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 
 // ------------------------------------------------------------------------------- host side
 
+// This file is compiled twice (build time: the instances are most of it): as itself -- host side + the byte-voxel
+// instances -- and through smk_slab_f32.hip (SLAB_PART 1) -- the float-voxel instances alone.
+#ifndef SLAB_PART
+#define SLAB_PART 0
+#endif
+#if SLAB_PART == 0
 static void host_ray(const RenderParams &P, int i, int j, double A[3], double B[3]) {
   const smk_raycoef &rc = P.rc;
   float px = fmaf((float)i + 0.5f, rc.pxs, rc.pxl), py = fmaf((float)j + 0.5f, rc.pys, rc.pyl);
@@ -1562,6 +1568,7 @@ bool slab_bundle_slice_range_exact(const RenderParams &P, double fx0, double fy0
   return true;
 }
 }  // namespace
+#endif  // SLAB_PART == 0
 
 template <int DT, int SH, int PERM, int NW, int NL, bool DIAG, int TF = 1, bool BR = true>
 static hipError_t launch_slab(const RenderParams &P, const SlabParams &Q, size_t lds, int nblocks, hipStream_t s) {
@@ -1579,6 +1586,70 @@ static hipError_t launch_slab(const RenderParams &P, const SlabParams &Q, size_t
 }
 
 // plan + launch; returns hipErrorNotSupported when the configuration must use the gather kernel
+
+// ---- instance dispatch, one function per voxel type (one translation unit each)
+hipError_t smk_slab_dispatch_u8(const RenderParams &P, const SlabParams &Q, int tf_mode, int shade_kind, int nw, int nl, bool diag, size_t lds,
+                                int nblocks, const char **why, hipStream_t s);
+hipError_t smk_slab_dispatch_f32(const RenderParams &P, const SlabParams &Q, int tf_mode, int shade_kind, int nw, int nl, bool diag, size_t lds,
+                                 int nblocks, const char **why, hipStream_t s);
+#if SLAB_PART == 0
+hipError_t smk_slab_dispatch_u8(const RenderParams &P, const SlabParams &Q, int tf_mode, int shade_kind, int nw, int nl, bool diag, size_t lds,
+                                int nblocks, const char **why, hipStream_t s) {
+  const int dtype = 0;
+#else
+hipError_t smk_slab_dispatch_f32(const RenderParams &P, const SlabParams &Q, int tf_mode, int shade_kind, int nw, int nl, bool diag, size_t lds,
+                                 int nblocks, const char **why, hipStream_t s) {
+  const int dtype = 1;
+#endif
+  (void)diag;
+#define GO(D, S, R, N, L)                                                                              \
+  if (dtype == D && shade_kind == S && Q.perm == R && nw == N && nl == L) {                          \
+    if (tf_mode == 2) {                                                                              \
+      if constexpr ((N == 8 && L == 2) || (N == 10 && L == 2) || (N == 12 && L == 4)) {              \
+        if (Q.bricks) return (launch_slab<D, S, R, N, L, false, 2, true>(P, Q, lds, nblocks, s));  \
+        return (launch_slab<D, S, R, N, L, false, 2, false>(P, Q, lds, nblocks, s));     \
+      }                                                                                              \
+      *why = "no dense-3-D-table instance for this tile size";                                       \
+      return hipErrorNotSupported;                                                                   \
+    }                                                                                                \
+    if (tf_mode == 0) {                                                                              \
+      if constexpr (S == 0 && ((N == 8 && L == 2) || (N == 10 && L == 2) || (N == 12 && L == 4)))    \
+        return (launch_slab<D, S, R, N, L, false, 0, false>(P, Q, lds, nblocks, s));     \
+      *why = "no colour-table instance for this tile size";                                          \
+      return hipErrorNotSupported;                                                                   \
+    }                                                                                                \
+    if constexpr (D == 1 && S == 1) {                                                                \
+      if (diag) return (launch_slab<D, S, R, N, L, true>(P, Q, lds, nblocks, s));        \
+    }                                                                                                \
+    if (Q.bricks) return (launch_slab<D, S, R, N, L, false, 1, true>(P, Q, lds, nblocks, s));  \
+    return (launch_slab<D, S, R, N, L, false, 1, false>(P, Q, lds, nblocks, s));         \
+  }
+  // product tile shapes: 32x16 px with 8+2 waves, 32x24 px with 12+4; the others are experiment knobs (option "tile")
+#ifdef SLAB_ALL_TILES
+#define GO_NW(D, S, R) GO(D, S, R, 4, 1) GO(D, S, R, 6, 2) GO(D, S, R, 8, 1) GO(D, S, R, 8, 2) GO(D, S, R, 8, 4) GO(D, S, R, 9, 2) GO(D, S, R, 12, 2) GO(D, S, R, 12, 4) GO(D, S, R, 8, 8) GO(D, S, R, 10, 6) GO(D, S, R, 10, 2)
+#else
+#define GO_NW(D, S, R) GO(D, S, R, 8, 2) GO(D, S, R, 10, 2) GO(D, S, R, 12, 4)
+#endif
+#define GO_R(D, S) GO_NW(D, S, 0) GO_NW(D, S, 1) GO_NW(D, S, 2)
+#if SLAB_PART == 0
+#ifndef SLAB_FEW_INSTANCES
+  GO_R(0, 0) GO_R(0, 1) GO_R(0, 2)
+#endif
+#else
+#ifdef SLAB_FEW_INSTANCES
+  GO_R(1, 1)
+#else
+  GO_R(1, 0) GO_R(1, 1) GO_R(1, 2)
+#endif
+#endif
+#undef GO_R
+#undef GO_NW
+#undef GO
+  *why = "no kernel instance for this tile size";
+  return hipErrorNotSupported;
+}
+
+#if SLAB_PART == 0
 hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kind, int opt_T, int opt_tile, int forced,
                            const void *vox_native, const void *vox_xmajor, SlabAux *aux, const char **why,
                            hipStream_t s) {
@@ -2122,48 +2193,12 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
       aux->ticks_pending_n = ticks_n_now;
       return hipSuccess;
     };
-#define GO(D, S, R, N, L)                                                                              \
-  if (dtype == D && shade_kind == S && Q.perm == R && nw == N && nl == L) {                          \
-    if (tf_mode == 2) {                                                                              \
-      if constexpr ((N == 8 && L == 2) || (N == 10 && L == 2) || (N == 12 && L == 4)) {              \
-        if (Q.bricks) return after_launch(launch_slab<D, S, R, N, L, false, 2, true>(P, Q, lds, nblocks, s));  \
-        return after_launch(launch_slab<D, S, R, N, L, false, 2, false>(P, Q, lds, nblocks, s));     \
-      }                                                                                              \
-      *why = "no dense-3-D-table instance for this tile size";                                       \
-      return hipErrorNotSupported;                                                                   \
-    }                                                                                                \
-    if (tf_mode == 0) {                                                                              \
-      if constexpr (S == 0 && ((N == 8 && L == 2) || (N == 10 && L == 2) || (N == 12 && L == 4)))    \
-        return after_launch(launch_slab<D, S, R, N, L, false, 0, false>(P, Q, lds, nblocks, s));     \
-      *why = "no colour-table instance for this tile size";                                          \
-      return hipErrorNotSupported;                                                                   \
-    }                                                                                                \
-    if constexpr (D == 1 && S == 1) {                                                                \
-      if (diag) return after_launch(launch_slab<D, S, R, N, L, true>(P, Q, lds, nblocks, s));        \
-    }                                                                                                \
-    if (Q.bricks) return after_launch(launch_slab<D, S, R, N, L, false, 1, true>(P, Q, lds, nblocks, s));  \
-    return after_launch(launch_slab<D, S, R, N, L, false, 1, false>(P, Q, lds, nblocks, s));         \
-  }
-  // product tile shapes: 32x16 px with 8+2 waves, 32x24 px with 12+4; the others are experiment knobs (option "tile")
-#ifdef SLAB_ALL_TILES
-#define GO_NW(D, S, R) GO(D, S, R, 4, 1) GO(D, S, R, 6, 2) GO(D, S, R, 8, 1) GO(D, S, R, 8, 2) GO(D, S, R, 8, 4) GO(D, S, R, 9, 2) GO(D, S, R, 12, 2) GO(D, S, R, 12, 4) GO(D, S, R, 8, 8) GO(D, S, R, 10, 6) GO(D, S, R, 10, 2)
-#else
-#define GO_NW(D, S, R) GO(D, S, R, 8, 2) GO(D, S, R, 10, 2) GO(D, S, R, 12, 4)
-#endif
-#define GO_R(D, S) GO_NW(D, S, 0) GO_NW(D, S, 1) GO_NW(D, S, 2)
-#ifdef SLAB_FEW_INSTANCES
-    GO_R(1, 1)
-#else
-    GO_R(0, 0) GO_R(0, 1) GO_R(0, 2) GO_R(1, 0) GO_R(1, 1) GO_R(1, 2)
-#endif
-#undef GO_R
-#undef GO_NW
-#undef GO
-    *why = "no kernel instance for this tile size";
-    return hipErrorNotSupported;
+    return after_launch(dtype == 0 ? smk_slab_dispatch_u8(P, Q, tf_mode, shade_kind, nw, nl, diag, lds, nblocks, why, s)
+                                   : smk_slab_dispatch_f32(P, Q, tf_mode, shade_kind, nw, nl, diag, lds, nblocks, why, s));
   }
   }  // pass
   (void)forced;
   *why = "no configuration fits";
   return hipErrorNotSupported;
 }
+#endif  // SLAB_PART == 0
