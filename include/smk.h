@@ -255,6 +255,13 @@ typedef struct {
 int smk_get_shadowcoef(smk_ctx *ctx, smk_shadowcoef *out);
 /* the light buffer as the last frame with shadows left it: [LB][LB][4] floats to HOST memory (synchronises) */
 int smk_get_light_buffer(smk_ctx *ctx, float *rgba_out, int *lb_out);
+/* Empty-space skipping (option "bricks", no reference counterpart: the reference draws every slice and lets the blend
+ * unit discard what the table made transparent, VolumeRenderer.cpp:507-741).  The flags the NEXT frame would use, for
+ * checkers: one byte per brick of 8x8x8 cells of this context's stored box, x fastest, 1 = some sample whose cell lies
+ * in the brick may be visible under the current table.  nb_out[3] receives the brick counts; flags_out may be NULL to
+ * ask for the counts alone; *in_use_out (may be NULL) tells whether frames use them (not for a 1-D colour table, with
+ * the option off, or once > 90 % of the bricks turned out flagged).  Needs volume, table and camera; synchronises. */
+int smk_get_brick_flags(smk_ctx *ctx, unsigned char *flags_out, int *nb_out, int *in_use_out);
 /* options (all optional; defaults in brackets):
  *   "kernel"   [0] 0 auto: both ray-marchers produce bit-identical frames, the first frames of a new
  *              configuration time one and the other and the faster is kept; 1 gather kernel (every

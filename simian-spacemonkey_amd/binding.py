@@ -18,7 +18,7 @@ ABI_SYMBOLS = [
     "smk_create", "smk_destroy", "smk_last_error", "smk_upload_volume",
     "smk_upload_volume_device", "smk_set_shard", "smk_set_clip", "smk_set_clip_plane", "smk_hist2d", "smk_hist2d_device", "smk_merge_fields_device", "smk_shard_order", "smk_set_tlut1d",
     "smk_set_tf2d", "smk_set_tf3d", "smk_set_camera", "smk_set_shading", "smk_set_sampling",
-    "smk_set_perturb", "smk_set_blend", "smk_set_shadow", "smk_get_shadowcoef", "smk_get_light_buffer", "smk_render", "smk_render_device", "smk_composite_over_device",
+    "smk_set_perturb", "smk_set_blend", "smk_set_shadow", "smk_get_shadowcoef", "smk_get_light_buffer", "smk_get_brick_flags", "smk_render", "smk_render_device", "smk_composite_over_device",
     "smk_make_vgh_device", "smk_normals_vgh_device", "smk_synth_volume_device",
     "smk_get_raycoef", "smk_set_option", "smk_last_frame_info", "smk_get_stat", "smk_get_trace", "smk_get_tf2d_effective",
     "smk_timing_reset", "smk_timing_read", "smk_last_frame_id", "smk_frame_failed",
@@ -131,6 +131,7 @@ def load_library():
     L.smk_set_shadow.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float]
     L.smk_get_shadowcoef.argtypes = [C.c_void_p, P(ShadowCoef)]
     L.smk_get_light_buffer.argtypes = [C.c_void_p, C.c_void_p, P(C.c_int)]
+    L.smk_get_brick_flags.argtypes = [C.c_void_p, C.c_void_p, P(C.c_int), P(C.c_int)]
     L.smk_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.smk_render_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.smk_composite_over_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, P(C.c_int), C.c_int,
@@ -346,6 +347,15 @@ class Renderer:
         out = np.zeros((lb.value, lb.value, 4), np.float32)
         self._ck(self.L.smk_get_light_buffer(self.ctx, out.ctypes.data_as(C.c_void_p), C.byref(lb)))
         return out
+
+    def brick_flags(self):
+        """(flags [nbz][nby][nbx] uint8, in_use) -- the empty-space flags the next frame would use (smk_get_brick_flags)"""
+        nb = (C.c_int * 3)()
+        use = C.c_int(0)
+        self._ck(self.L.smk_get_brick_flags(self.ctx, None, nb, C.byref(use)))
+        out = np.zeros((nb[2], nb[1], nb[0]), np.uint8)
+        self._ck(self.L.smk_get_brick_flags(self.ctx, out.ctypes.data_as(C.c_void_p), nb, C.byref(use)))
+        return out, bool(use.value)
 
     def set_option(self, key, value):
         self._ck(self.L.smk_set_option(self.ctx, key.encode(), int(value)))

@@ -1083,6 +1083,23 @@ static int take_status(smk_ctx *c, int slot) {
   return st;
 }
 
+static int build_params(smk_ctx *c, RenderParams &P, hipStream_t s);
+extern "C" int smk_get_brick_flags(smk_ctx *c, unsigned char *flags_out, int *nb_out, int *in_use_out) {
+  if (!c || !nb_out) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  RenderParams P;
+  if (build_params(c, P, c->stream)) return 1;
+  HIPCHK(c, hipDeviceSynchronize());
+  for (int a = 0; a < 3; ++a) nb_out[a] = c->nbr[a];
+  const BrickSet *B = c->tf_mode == 1 && c->tf_cur >= 0 ? &c->tfv[c->tf_cur].br : c->tf_mode == 2 ? &c->br3 : nullptr;
+  if (in_use_out) *in_use_out = P.bricks != nullptr ? 1 : 0;
+  if (flags_out) {
+    if (!B || !B->valid || !B->flags) FAIL(c, "smk_get_brick_flags: no flags for this table (1-D colour table, or option 'bricks' 0)");
+    HIPCHK(c, hipMemcpy(flags_out, B->flags, (size_t)c->nbr[0] * c->nbr[1] * c->nbr[2], hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
 static int check_slab_status(smk_ctx *c) {
   for (int k = 0; k < SMK_STATUS_RING; ++k) {
     const int st = take_status(c, k);

@@ -180,3 +180,30 @@ def test_perturbed_fetch(R, kind, weights):
     sc.noise = None
     push_scene(R, sc)
     R.set_option("bricks", 1)
+
+
+@pytest.mark.parametrize("kind,f32,dims", [("cfg3", True, None), ("cfg3", False, None), ("cfg2", False, None), ("cfg4", True, None),
+                                           ("tf3d_panes", True, None), ("cfg3", True, (41, 23, 70))])
+def test_flags_equal_the_numpy_restatement(R, kind, f32, dims):
+    """the flags themselves, byte for byte, against oracle/bricks.py (value ranges over the voxels a brick's cells touch,
+    the occupancy bitmap of the EFFECTIVE table, the summed-area range test widened by one texel)"""
+    import bricks as B      # oracle/bricks.py
+    sc = make_scene(kind, n=48, size=64, steps=96, pose="rot", f32=f32, shade=1, dims=dims)
+    R.set_option("bricks", 1)
+    push_scene(R, sc)
+    got, in_use = R.brick_flags()
+    vol = sc.data
+    if vol.dtype == np.uint8:
+        v = vol[..., 0].astype(np.float32) * np.float32(1.0 / 255.0)
+        g = vol[..., 1].astype(np.float32) * np.float32(1.0 / 255.0)
+    else:
+        v, g = vol[..., 0].astype(np.float32), vol[..., 1].astype(np.float32)
+    if sc.tf_mode == 2:
+        occ = B.fold_occupancy(sc.tf3d[..., 3])
+    else:
+        eff, _ = R.tf2d_effective(sc.tf_vg.shape[1], sc.tf_vg.shape[0])
+        occ = B.occupancy(eff[..., 3])
+    want = B.brick_flags(np.ascontiguousarray(v), np.ascontiguousarray(g), occ)
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), "%d of %d flags differ" % ((got != want).sum(), got.size)
+    assert in_use == (want.mean() <= 0.9) or in_use    # (dropped only once the count came back above 90 %)
