@@ -525,30 +525,40 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
     // bricks from it on, as a 64-bit mask -- kept in the ring's memory, which nobody uses before the last barrier
     uint4 *lmask = reinterpret_cast<uint4 *>(smem);
     const int nlay = ((Q.Ds - 1) >> BL) + 1;
-    for (int bl0 = wave * 4; bl0 < nlay; bl0 += (NW + NL) * 4) {
-      int bu0[4], bv0[4];
-      unsigned f[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int bl = bl0 + k;
-        int ulo = 0x7fffffff, vlo = 0x7fffffff;
-        if (bl < nlay)
-          for (int e = bl << BL; e < min((bl + 1) << BL, Q.Ds); ++e) {
-            const int sl = e + Q.Os;
-            if (sl < smin || sl > smax + 1) continue;
-            const unsigned pk = wtab[e].pack;
-            ulo = min(ulo, (int)(pk & 0x7ffu));
-            vlo = min(vlo, (int)((pk >> 11) & 0x7ffu));
-          }
-        bu0[k] = ulo >> BL;
-        bv0[k] = vlo >> BL;
-        f[k] = 0;
-        const int bu = bu0[k] + (lane & 7), bv = bv0[k] + (lane >> 3);
-        if (ulo != 0x7fffffff && bu <= ((Q.Du - 1) >> BL) && bv <= ((Q.Dv - 1) >> BL))
-          f[k] = Q.bricks[(size_t)bl * Q.bss + (size_t)bv * Q.bsv + (size_t)bu * Q.bsu];
+    // (eight layers per wave and round, so that a workgroup's loads are all in flight at once: lane 8 k + j reads the
+    //  window origin of slice j of layer k, the eight lanes of a group reduce to the layer's origin; two rounds of four
+    //  layers with every lane looping over the entries took 9-10 us of the set-up's 19)
+    static_assert(SMK_BRICK_LOG2 == 3, "the lane mapping below assumes eight slices per layer of bricks");
+    for (int bl0 = wave * 8; bl0 < nlay; bl0 += (NW + NL) * 8) {
+      int ulo = 0x7fffffff, vlo = 0x7fffffff;
+      {
+        const int e = ((bl0 + (lane >> 3)) << BL) + (lane & 7);
+        const int sl = e + Q.Os;
+        if (e < Q.Ds && sl >= smin && sl <= smax + 1) {
+          const unsigned pk = wtab[e].pack;
+          ulo = (int)(pk & 0x7ffu);
+          vlo = (int)((pk >> 11) & 0x7ffu);
+        }
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int o = 1; o < 8; o <<= 1) {
+        ulo = min(ulo, __shfl_xor(ulo, o));
+        vlo = min(vlo, __shfl_xor(vlo, o));
+      }
+      int bu0[8], bv0[8];
+      unsigned f[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int lu = __builtin_amdgcn_readlane(ulo, k * 8), lv = __builtin_amdgcn_readlane(vlo, k * 8);
+        bu0[k] = lu >> BL;
+        bv0[k] = lv >> BL;
+        f[k] = 0;
+        const int bu = bu0[k] + (lane & 7), bv = bv0[k] + (lane >> 3);
+        if (bl0 + k < nlay && lu != 0x7fffffff && bu <= ((Q.Du - 1) >> BL) && bv <= ((Q.Dv - 1) >> BL))
+          f[k] = Q.bricks[(size_t)(bl0 + k) * Q.bss + (size_t)bv * Q.bsv + (size_t)bu * Q.bsu];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
         const unsigned long long m = __ballot(f[k] != 0);
         if (lane == 0 && bl0 + k < nlay) lmask[bl0 + k] = make_uint4((unsigned)bu0[k], (unsigned)bv0[k], (unsigned)m, (unsigned)(m >> 32));
       }
