@@ -616,7 +616,14 @@ def main():
                    "parallelism": "sort-last x%d (brick shards; RCCL all-to-all + ordered over + gather, two "
                                   "frames in flight: frame i's exchange overlaps frame i+1's ray-marching)" % world
                    if world > 1 else "single GPU",
-                   "kernel": {1: "gather", 2: "slab-staged"}.get(kernel, str(kernel))},
+                   "kernel": {1: "gather", 2: "slab-staged"}.get(kernel, str(kernel)),
+                   # what the frame does NOT do, said on the line itself: bricks of 8x8x8 cells in which no sample can be
+                   # visible under the table are neither streamed nor sampled.  Every sample that is dropped
+                   # is exactly transparent -- the frame is compared bit for bit with the flags-off one in this very run
+                   # (`without_brick_flags`, which is also the leg to read for the streaming kernel's own roofline).  The
+                   # flags are made per volume upload (value ranges) and per table refresh (two launches, ~0.1 ms of stream
+                   # time); volume and table are static here, so neither falls into the timed steps.
+                   "empty_space_skipping": "on (option bricks=1, the default)" if flags_on else "off (SMK_BENCH_BRICKS=0)"},
     }
     if rank == 0:
         out["roofline"] = roofline(r, kms, alg_bytes, size,
