@@ -207,3 +207,43 @@ def test_flags_equal_the_numpy_restatement(R, kind, f32, dims):
     assert got.shape == want.shape
     assert np.array_equal(got, want), "%d of %d flags differ" % ((got != want).sum(), got.size)
     assert in_use == (want.mean() <= 0.9) or in_use    # (dropped only once the count came back above 90 %)
+
+
+def test_a_table_edited_every_frame_without_synchronising(R):
+    """the interactive case: a new table AND a new correction rate every frame, frames enqueued without waiting (the raw
+    table, its effective versions, their bitmaps and brick flags all rotate behind stream events); every eighth frame
+    is compared with the gather kernel's, flags off, after the fact"""
+    import torch
+    sc = make_scene("cfg3", n=64, size=96, steps=128, pose="rot", f32=True, shade=1)
+    R.set_option("bricks", 1)
+    push_scene(R, sc)
+    R.set_option("kernel", 2)
+    rng = np.random.default_rng(11)
+    frames = [torch.zeros((96 * 96, 4), dtype=torch.float32, device="cuda") for _ in range(5)]
+    kept = []
+    for f in range(40):
+        tf = np.zeros((256, 256, 4), np.uint8)
+        lo = int(rng.integers(20, 200))
+        tf[int(rng.integers(0, 100)):int(rng.integers(120, 256)), lo:lo + int(rng.integers(4, 50))] = (
+            int(rng.integers(30, 255)), int(rng.integers(30, 255)), 60, int(rng.integers(1, 255)))
+        steps = 100 + (f * 7) % 60
+        R.set_tf2d(tf, None)
+        R.set_sampling(0.0, steps, 1.0, 1)
+        keep = f % 8 == 7
+        R.render_device(frames[len(kept) if keep else 4].data_ptr())
+        if keep:
+            kept.append((tf, steps))
+    torch.cuda.synchronize()
+    assert R.stat("slab_failures") == 0
+    R.set_option("kernel", 1)
+    R.set_option("bricks", 0)
+    for k, (tf, steps) in enumerate(kept):
+        R.set_tf2d(tf, None)
+        R.set_sampling(0.0, steps, 1.0, 1)
+        ref = R.render().reshape(-1, 4)
+        got = frames[k].cpu().numpy()
+        assert np.array_equal(got, ref), "frame %d differs by %g" % (k, np.abs(got - ref).max())
+        assert ref[:, 3].max() > 0
+    R.set_option("kernel", 0)
+    R.set_option("bricks", 1)
+    push_scene(R, sc)
