@@ -77,6 +77,7 @@ static void free_volume(smk_ctx *c) {
   if (c->d_nrm) (void)hipFree(c->d_nrm);
   if (c->d_vox_x) (void)hipFree(c->d_vox_x);
   if (c->d_brick_mm) (void)hipFree(c->d_brick_mm);
+  smk_cols_drop_layouts(&c->cols);  // (built from this volume)
   c->d_brick_mm = nullptr;
   c->d_vox_x = nullptr;
   c->d_vox = nullptr;
@@ -98,6 +99,7 @@ extern "C" void smk_destroy(smk_ctx *c) {
   }
   if (c->tf_raw_ev) (void)hipEventDestroy(c->tf_raw_ev);
   free_brick_set(c->br3);
+  smk_cols_free(&c->cols);
   void *ptrs[] = {c->d_tf_raw, c->d_tlut, c->d_tf_h, c->d_tf3d, c->d_tf3d_occ, c->d_noise, c->d_out, c->d_depth, c->d_light[0], c->d_light[1]};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -1019,6 +1021,11 @@ extern "C" int smk_set_option(smk_ctx *c, const char *key, int value) {
   else if (!strcmp(key, "slab_sched")) c->opt_slab_sched = value < 0 ? 0 : (value > 15 ? 15 : value);
   else if (!strcmp(key, "slab_ns")) c->opt_slab_ns = value < 0 ? 0 : (value > 63 ? 63 : value);
   else if (!strcmp(key, "tile")) c->opt_tile = value;
+  else if (!strcmp(key, "cols_shape")) c->opt_cols = (c->opt_cols & ~0xff) | (value & 0xff);
+  else if (!strcmp(key, "cols_ns")) c->opt_cols = (c->opt_cols & ~0xff00) | ((value & 0xff) << 8);
+  else if (!strcmp(key, "cols_chunk")) c->opt_cols = (c->opt_cols & ~0xfff0000) | ((value & 0xfff) << 16);
+  else if (!strcmp(key, "cols_wstep")) c->opt_cols = (c->opt_cols & 0x0fffffff) | ((value & 7) << 28);
+  else if (!strcmp(key, "cols_counts")) c->cols.want_counts = value ? 1 : 0;
   else if (!strcmp(key, "bricks")) {  // 0: the slice-ring kernel streams and samples every slice (smk_bricks.hip off)
     c->opt_bricks = value ? 1 : 0;
     c->tf_dirty = true;
@@ -1103,7 +1110,7 @@ extern "C" int smk_get_brick_flags(smk_ctx *c, unsigned char *flags_out, int *nb
 static int check_slab_status(smk_ctx *c) {
   for (int k = 0; k < SMK_STATUS_RING; ++k) {
     const int st = take_status(c, k);
-    if (st) FAIL(c, "slice-ring kernel reported %s (status %d); frame invalid", st == 1 ? "a producer/consumer time-out" : "a window outside its host bound", st);
+    if (st) FAIL(c, "%s (status %d); frame invalid", st == 1 ? "a streaming kernel reported a producer/consumer time-out" : st == 2 ? "the slice-ring kernel reported a window outside its host bound" : st == 3 ? "the column-stream kernel reported a column footprint wider than its lane lattice" : "the column-stream kernel reported a failed ray search", st);
   }
   return 0;
 }
@@ -1181,6 +1188,41 @@ extern "C" int smk_get_stat(smk_ctx *c, const char *name, double *value) {
       *value = (name[13] == 'm' ? mx : sum) * 1e-5;  // 100 MHz ticks
     }
     return 0;
+  }
+  // column-stream kernel (smk_cols.hip), latest frame; these synchronise
+  if (!strncmp(name, "cols_", 5)) {
+    *value = 0.0;
+    if (!strcmp(name, "cols_builds")) { *value = c->cols.builds; return 0; }
+    if (!strcmp(name, "cols_config")) { *value = c->cols.last; return 0; }
+    if (!strcmp(name, "cols_jobs")) { *value = c->cols.njobs_last; return 0; }
+    if (!strcmp(name, "cols_stream_bytes")) { *value = c->cols.last_stream_bytes; return 0; }
+    if (!strcmp(name, "cols_job_ms_max") || !strcmp(name, "cols_job_ms_sum")) {
+      const int nj = c->cols.njobs_last;
+      if (c->last_kernel == 4 && c->cols.d_ticks && nj > 0) {
+        HIPCHK(c, hipDeviceSynchronize());
+        std::vector<unsigned> h((size_t)nj);
+        HIPCHK(c, hipMemcpy(h.data(), c->cols.d_ticks, (size_t)nj * 4, hipMemcpyDeviceToHost));
+        double mx = 0, sum = 0;
+        for (int t = 0; t < nj; ++t) {
+          mx = std::max(mx, (double)h[t]);
+          sum += h[t];
+        }
+        *value = (name[12] == 'm' ? mx : sum) * 1e-5;
+      }
+      return 0;
+    }
+    static const char *cn[4] = {"cols_samples", "cols_visible", "cols_slices", "cols_segments"};
+    for (int k = 0; k < 4; ++k)
+      if (!strcmp(name, cn[k])) {
+        if (c->cols.d_counts && c->cols.want_counts) {
+          HIPCHK(c, hipDeviceSynchronize());
+          unsigned long long v = 0;
+          HIPCHK(c, hipMemcpy(&v, c->cols.d_counts + k, 8, hipMemcpyDeviceToHost));
+          *value = (double)v;
+        }
+        return 0;
+      }
+    FAIL(c, "smk_get_stat: unknown name '%s'", name);
   }
   if (!strcmp(name, "slab_retries")) {
     *value = (double)c->slab_retries;
@@ -1521,6 +1563,29 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
         trial = c->tune_state;  // 0,1: untimed first launches (one-time set-up), 2,3: the timed pair
         try_slab = (trial & 1) == 0;
       }
+    }
+  }
+  if (c->opt_kernel == 3) {
+    // ---- the column-stream kernel, forced (smk_cols.hip)
+    try_slab = false;
+    if (!c->slab.h_status) {
+      HIPCHK(c, hipHostMalloc((void **)&c->slab.h_status, SMK_STATUS_RING * sizeof(int), hipHostMallocMapped));
+      for (int k = 0; k < SMK_STATUS_RING; ++k) c->slab.h_status[k] = 0;
+      HIPCHK(c, hipMalloc((void **)&c->slab.d_diag, 16 * sizeof(float)));
+    }
+    const char *why = nullptr;
+    c->cols.frame_ev0 = c->ev0;
+    hipError_t e = smk_launch_cols(P, c->dtype, c->tf_mode, shade_kind_of(c), c->opt_cols, c->d_vox, &c->cols,
+                                   c->slab.h_status + c->slab.status_slot, &why, s);
+    if (e == hipErrorNotSupported) {
+      c->slab_why = why ? why : "?";
+      FAIL(c, "smk_render: column-stream kernel forced but not applicable: %s", c->slab_why.c_str());
+    }
+    HIPCHK(c, e);
+    c->last_kernel = 4;
+    if (c->opt_inject_status && c->slab.h_status) {
+      ((volatile int *)c->slab.h_status)[c->slab.status_slot] = c->opt_inject_status;
+      c->opt_inject_status = 0;
     }
   }
   if (try_slab) {

@@ -105,6 +105,33 @@ struct SlabAux {
   int trace_cap = 0, trace_n = 0;
 };
 
+// the column-stream kernel's side buffers (smk_cols.hip), owned by the context
+struct ColLayout {  // the stored box re-laid out for one principal axis: [cv][cu][s][(CH+1)][(CW+1)] voxels
+  void *d = nullptr;
+  size_t bytes = 0;
+  int CW = 0, CH = 0, ncu = 0, ncv = 0, Du = 0, Dv = 0, Ds = 0, slice_bytes = 0, vb = 0;
+  const void *src = nullptr;  // the native volume it was built from
+};
+struct ColsAux {
+  ColLayout lay[3];             // per principal axis (perm 0: S = z, 1: S = y, 2: S = x), built on first use
+  void *d_layers = nullptr;     // [nkeys][npix] float4: a ray's partial composites, one per job it crosses
+  size_t layers_cap = 0;
+  void *d_masks = nullptr;      // [npix][mask_words] bit per key written
+  size_t masks_cap = 0;
+  bool masks_dirty = true;
+  int mask_words_last = 0;
+  unsigned *d_ticks = nullptr;  // [njobs] workgroup durations of the latest frame (100 MHz ticks)
+  int ticks_cap = 0, njobs_last = 0;
+  unsigned long long *d_counts = nullptr;  // [4] samples taken | visible | slices streamed | segments written
+  int want_counts = 0;
+  int builds = 0;               // layouts built so far
+  int last = 0;                 // CW | CH << 8 | nslots << 16 | shape << 24 of the latest launch
+  double last_stream_bytes = 0; // bytes the loaders of the latest launch had to stream
+  hipEvent_t frame_ev0 = nullptr;
+};
+void smk_cols_free(ColsAux *aux);
+void smk_cols_drop_layouts(ColsAux *aux);
+
 hipError_t smk_bricks_dilate(const unsigned char *flags, const int nb[3], const int r[3], unsigned char *out, hipStream_t s);
 // the flags of one table (version): buffers, and how many bricks came out flagged (copied back behind the kernel)
 struct BrickSet {
@@ -227,6 +254,8 @@ struct smk_ctx {
   int opt_inject_status = 0;  // (test hook) the next slice-ring frame reports this status word
   int opt_wave_w = 8, opt_blk_w = 2, opt_lockstep = 1;
   SlabAux slab;  // slice-ring kernel side buffers
+  ColsAux cols;  // column-stream kernel side buffers
+  int opt_cols = 0;  // developer knobs of the column-stream kernel: shape | slots << 8 | chunk << 16 | (wstep + 1) << 28
   // auto mode (option kernel = 0) picks the ray-marcher by measurement: the first frames of a
   // new configuration run the slice-ring kernel, then the gather kernel (bit-identical frames),
   // and the faster one is kept for that configuration
@@ -258,3 +287,6 @@ hipError_t smk_launch_shadow(const RenderParams &P, const smk_shadowcoef &sc, in
 hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kind, int opt_T, int opt_tile, int forced,
                            const void *vox_native, const void *vox_xmajor, SlabAux *aux, const char **why,
                            hipStream_t s);
+// the column-stream kernel (smk_cols.hip); same convention as smk_launch_slab
+hipError_t smk_launch_cols(RenderParams P, int dtype, int tf_mode, int shade_kind, int knobs, const void *vox_native, ColsAux *aux,
+                           int *status_word, const char **why, hipStream_t s);

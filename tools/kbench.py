@@ -91,6 +91,15 @@ def main():
         print("%-32s kernel=%d  %.3f ms/frame  (event avg %.3f ms)  %.1f GB/s alg  frac %.3f  maxdiff_vs_first %.2e  alpha_mean %.4f"
               % (var, kern, t / a.frames * 1e3, kms, alg / (kms * 1e-3) / 1e9, alg / (kms * 1e-3) / 1e9 / 8000, err, img[:, 3].mean()),
               flush=True)
+        if kern == 4:
+            cfg = int(r.stat("cols_config"))
+            sb = r.stat("cols_stream_bytes")
+            print("   column-stream: CW x CH %d x %d, %d slots, shape %d, %d jobs; streamed %.2f GB = %.2f x alg -> %.0f GB/s; jobs: longest %.3f ms, sum %.1f ms (= %.3f ms per CU of 256); layouts built %d" %
+                  (cfg & 255, (cfg >> 8) & 255, (cfg >> 16) & 255, cfg >> 24, r.stat("cols_jobs"), sb / 1e9, sb / alg, sb / (kms * 1e-3) / 1e9,
+                   r.stat("cols_job_ms_max"), r.stat("cols_job_ms_sum"), r.stat("cols_job_ms_sum") / 256, r.stat("cols_builds")), flush=True)
+            if any(kv.split("=")[0] == "cols_counts" and int(kv.split("=")[1]) for kv in var.split(",")):
+                print("   samples taken %.4g, visible %.4g, slices streamed %.4g, segments %.4g" %
+                      (r.stat("cols_samples"), r.stat("cols_visible"), r.stat("cols_slices"), r.stat("cols_segments")), flush=True)
         if kern == 2:
             print("   workgroups: longest %.3f ms, sum %.1f ms (= %.3f ms on every workgroup slot of 256 CUs x 2)" %
                   (r.stat("slab_tile_ms_max"), r.stat("slab_tile_ms_sum"), r.stat("slab_tile_ms_sum") / 512), flush=True)
