@@ -1026,6 +1026,10 @@ extern "C" int smk_set_option(smk_ctx *c, const char *key, int value) {
   else if (!strcmp(key, "cols_chunk")) c->opt_cols = (c->opt_cols & ~0xfff0000) | ((value & 0xfff) << 16);
   else if (!strcmp(key, "cols_wstep")) c->opt_cols = (c->opt_cols & 0x0fffffff) | ((value & 7) << 28);
   else if (!strcmp(key, "cols_counts")) c->cols.want_counts = value ? 1 : 0;
+  else if (!strcmp(key, "cols_fill")) { c->cols.opt_fill = value; smk_cols_drop_layouts(&c->cols); }
+  else if (!strcmp(key, "cols_take_min")) c->cols.opt_take_min = value;
+  else if (!strcmp(key, "cols_take_wait")) c->cols.opt_take_wait = value;
+  else if (!strcmp(key, "cols_fly")) c->cols.opt_fly = value;
   else if (!strcmp(key, "bricks")) {  // 0: the slice-ring kernel streams and samples every slice (smk_bricks.hip off)
     c->opt_bricks = value ? 1 : 0;
     c->tf_dirty = true;
@@ -1196,6 +1200,18 @@ extern "C" int smk_get_stat(smk_ctx *c, const char *name, double *value) {
     if (!strcmp(name, "cols_config")) { *value = c->cols.last; return 0; }
     if (!strcmp(name, "cols_jobs")) { *value = c->cols.njobs_last; return 0; }
     if (!strcmp(name, "cols_stream_bytes")) { *value = c->cols.last_stream_bytes; return 0; }
+    if (!strcmp(name, "cols_setup_ms_sum") || !strcmp(name, "cols_rays")) {
+      const int nj = c->cols.njobs_last;
+      if (c->last_kernel == 4 && c->cols.d_ticks && nj > 0) {
+        HIPCHK(c, hipDeviceSynchronize());
+        std::vector<unsigned> h((size_t)nj);
+        HIPCHK(c, hipMemcpy(h.data(), c->cols.d_ticks + (size_t)nj * (name[5] == 's' ? 1 : 2), (size_t)nj * 4, hipMemcpyDeviceToHost));
+        double sum = 0;
+        for (int t = 0; t < nj; ++t) sum += h[t];
+        *value = name[5] == 's' ? sum * 1e-5 : sum;
+      }
+      return 0;
+    }
     if (!strcmp(name, "cols_job_ms_max") || !strcmp(name, "cols_job_ms_sum")) {
       const int nj = c->cols.njobs_last;
       if (c->last_kernel == 4 && c->cols.d_ticks && nj > 0) {
@@ -1211,8 +1227,8 @@ extern "C" int smk_get_stat(smk_ctx *c, const char *name, double *value) {
       }
       return 0;
     }
-    static const char *cn[4] = {"cols_samples", "cols_visible", "cols_slices", "cols_segments"};
-    for (int k = 0; k < 4; ++k)
+    static const char *cn[8] = {"cols_samples", "cols_visible", "cols_slices", "cols_segments", "cols_iters", "cols_active_lanes", "cols_switch_iters", "cols_switch_lanes"};
+    for (int k = 0; k < 8; ++k)
       if (!strcmp(name, cn[k])) {
         if (c->cols.d_counts && c->cols.want_counts) {
           HIPCHK(c, hipDeviceSynchronize());

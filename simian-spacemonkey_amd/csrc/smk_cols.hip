@@ -17,10 +17,10 @@
 //   * job = one column x one chunk of CL slice positions; a workgroup per job: NL loader waves stream the chunk into an
 //     LDS ring, NW consumer waves sample it.  All jobs are the same length, there are thousands of them, none depends
 //     on another: no tile schedule, no longest workgroup;
-//   * rays pass THROUGH columns.  A lane is a slot of a La x Lb lattice in pixel space: at slice position p it holds
-//     the pixel congruent to its slot inside a box that slides with the column's footprint (exact per position, made
-//     in the job's set-up from the projected corners of the cell box); when the box drops a pixel the lane writes
-//     that ray's partial composite -- the "segment" of (ray, job) -- and takes the pixel that entered;
+//   * rays pass THROUGH columns.  In its set-up a job lists the rays that cross its cell box, each with the exact
+//     interval of planes whose samples belong to the box, sorted by the position they enter at; a consumer lane
+//     without a ray takes the next one of the list, marches it (no membership test in the loop: every sample it takes
+//     is the ray's), and writes the ray's partial composite -- the "segment" of (ray, job) -- when the ray leaves;
 //   * segments of a ray are keyed by the job's place along the ray (monotone in column indices and chunk), stored in
 //     layers[key][pixel] with a bit per key in a per-pixel mask; the resolve pass blends a pixel's segments in key
 //     order (front to back "over", or max) and clears the mask.
@@ -54,7 +54,8 @@ struct ColParams {
   int n_ch;                   // DMA wave-instructions per slice = ceil(slice_bytes / 1024)
   unsigned long long last_mask;  // lanes of the last one
   int nslots, maxfly, wstep;
-  int ring_bytes;             // LDS bytes in front of the table: the ring, at least the set-up's scratch (6 x COL_MAX_CL words)
+  int take_min, take_wait;    // a wave takes new rays when this many lanes are free, or after this many turns
+  int ring_bytes;             // LDS bytes in front of the tables: the ring, at least the set-up's scratch (the unsorted rays)
   int CL, nck;                // positions per chunk, chunks
   int dir;                    // +1: rays advance towards +S
   float Mx[4], My[4], Mw[4];  // voxel (global coordinates) -> continuous pixel: x = Mx.(X,1) / Mw.(X,1)
@@ -64,7 +65,8 @@ struct ColParams {
   int use_ah, use_occ, fast_tf;
   int *status;                // host-visible: 1 protocol time-out, 3 lattice too small for a job's footprint, 4 set-up search failed
   unsigned *job_ticks;        // [njobs] duration of each job's workgroup in 100 MHz ticks, or null
-  unsigned long long *counts; // [4] samples taken | samples visible | slices streamed | segments written (developer statistics)
+  unsigned long long *counts; // [8] samples taken | visible | slices streamed | segments written | consumer wave-iterations | lanes with a sample to
+                              // take in them | iterations in which some lane changes rays | lanes changing rays (developer statistics)
 };
 
 typedef float c_v4f __attribute__((ext_vector_type(4)));
@@ -110,11 +112,14 @@ __device__ __forceinline__ void col_raw_lds_st_b32(void *p, int v) {
   unsigned a = (unsigned)(size_t)(c_lds_cptr_t)p;
   asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
 }
+// minimum over the 64 lanes of a fully active wave on the DPP network: v_min with a DPP operand (left to hipcc each step is
+// v_mov + s_nop + v_mov_dpp + v_min)
 __device__ __forceinline__ int col_wave_min(int v) {
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
-  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+  asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+               : "+v"(v));
   return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
              min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
@@ -139,44 +144,50 @@ __device__ __forceinline__ float col_tex_chan(const ColTexel4 &x, int k) {
   return smk_lerp(smk_lerp(smk_ub(x.a, k), smk_ub(x.b, k), x.fs), smk_lerp(smk_ub(x.c, k), smk_ub(x.d, k), x.fs), x.ft) * SMK_INV255;
 }
 
-// per-slice table entry of a job (index e = stored slice - the job's lowest slice)
-struct ColEnt {
-  int addr;  // LDS byte address of the slice's slot image
-  int box;   // origin of the pixel box of the position whose BASE slice this is: a0 (low 16 bits, signed) | b0 << 16
-};
+#define COL_MAX_RAYS 4096   // rays one job can list (8 bytes each in LDS)
 
-// one ray's marching state (registers; R of them per lane)
+// one ray's marching state (registers)
 struct ColRay {
   int i, j;
   float A[3], B[3];
-  int m;        // plane of the next sample
-  int pb;       // its position relative to the job's first (marching order), COL_DONE = none
-  float sc;     // clamped principal-axis coordinate of the next sample
-  int bi;       // and its base slice (global index)
+  int m, m_out;  // plane of the next sample, last plane of the ray inside this job
+  int pb;        // position of the next sample relative to the job's first (marching order); COL_DONE = the lane has no ray
+  float sc;      // clamped principal-axis coordinate of the next sample
+  int bi;        // and its base slice (global index)
   float C0, C1, C2, C3;
 };
 
-// NW consumer waves, NL loader waves; WA = lattice blocks of 8 slots along the image's x; R = rays per lane.
-// Lattice: La = 8 WA columns x Lb = R * 8 (NW / WA) rows; wave w, lane l, ray r sits at
-// (8 (w % WA) + (l & 7), r * 8 (NW / WA) + 8 (w / WA) + (l >> 3)): a wave is an 8 x 8 block of slots, so a box move that
-// replaces one lattice row or column makes eight lanes of a wave change rays together.
-template <int DT, int SH, int PERM, int TF, int NW, int NL, int WA, int R>
+// NW consumer waves, NL loader waves.
+//
+// Set-up, per job: every pixel whose ray can cross the job's cell box (the bounding box of its eight projected corners)
+// gets the exact interval [m_in, m_out] of planes whose sample has its base cell in the box and passes the gather
+// kernel's membership test -- coordinates are monotone in the plane index, so it IS an interval, found by bracketing
+// and testing the ends with the very fma chains the samples use -- and the rays that have one are listed in LDS in
+// the order of their first position.  Marching: a lane without a ray takes the next one of the list (the list is
+// sorted by entry, so everything taken later enters later: the head's entry bounds the ring's tail); every sample a
+// lane takes is one of its ray's, no test in the loop; a ray that ends writes its segment.
+template <int DT, int SH, int PERM, int TF, int NW, int NL>
 __global__ __launch_bounds__((NW + NL) * 64) void smk_k_cols(const RenderParams P, const ColParams Q) {
   constexpr int VB = DT == 0 ? 8 : 16;
   constexpr int NTH = (NW + NL) * 64;
-  constexpr int La = 8 * WA, Lb1 = 8 * (NW / WA), Lb = R * Lb1;
-  static_assert(NW % WA == 0, "the consumer waves tile the lattice");
   constexpr int AS = PERM == 0 ? 2 : (PERM == 1 ? 1 : 0);
   constexpr int AU = PERM == 2 ? 1 : 0;
   constexpr int AV = PERM == 0 ? 1 : 2;
   extern __shared__ __align__(16) unsigned char smem[];
   const int slot_stride = Q.slice_bytes;
-  ColEnt *tab = reinterpret_cast<ColEnt *>(smem + (size_t)Q.ring_bytes);  // [COL_MAX_CL + 2]; ring_bytes >= nslots * slice_bytes and >= the set-up scratch
-  // control words: [0] error flag  [4..4+NL) landed per loader  [8..8+16) progress per consumer wave
-  int *ctl = reinterpret_cast<int *>(tab + (COL_MAX_CL + 2));
+  // LDS: ring | ray list [COL_MAX_RAYS] uint2 | entry position of each listed ray [COL_MAX_RAYS] u8 | slot address of each of
+  // the job's slices [COL_MAX_CL + 1] | histogram / cursors [COL_MAX_CL + 1] | control words [32] | alpha_H | occupancy bitmap
+  uint2 *list = reinterpret_cast<uint2 *>(smem + (size_t)Q.ring_bytes);
+  unsigned char *epos = reinterpret_cast<unsigned char *>(list + COL_MAX_RAYS);
+  int *slot_addr = reinterpret_cast<int *>(epos + COL_MAX_RAYS);
+  int *hist = slot_addr + (COL_MAX_CL + 4);
+  // control words: [0] error flag  [1] list head  [2] rays listed  [3] candidates' scratch count  [4..8) landed per loader
+  // [8..24) progress per consumer wave
+  int *hist2 = hist + (COL_MAX_CL + 4);  // exits per position (set-up: the lanes must hold every ray that is inside at one position)
+  int *ctl = hist2 + (COL_MAX_CL + 4);
   float *ah = reinterpret_cast<float *>(ctl + 32);
   const uint32_t *occ = reinterpret_cast<const uint32_t *>(ah + (Q.use_ah ? P.sv : 0));
-  int *scratch = reinterpret_cast<int *>(smem);  // set-up only (the ring is not in use yet): [4][COL_MAX_CL] pixel bounds
+  uint4 *tmp = reinterpret_cast<uint4 *>(smem);  // set-up only (the ring is not in use yet): unsorted rays {ij, m_in, m_out, entry}
 
   const unsigned t_begin = (unsigned)__builtin_amdgcn_s_memrealtime();
   const int job = blockIdx.x;
@@ -186,112 +197,222 @@ __global__ __launch_bounds__((NW + NL) * 64) void smk_k_cols(const RenderParams 
   const bool is_loader = wave >= NW;
   const int NS = P.N[AS], NU = P.N[AU], NV = P.N[AV];
   const int dir = Q.dir;
+  const smk_raycoef &rc = P.rc;
   // positions (marching order) of the whole stored box: 0 .. Ds-2; base slice (stored) of position g = dir > 0 ? g : Ds-2-g
   const int pa = ck * Q.CL;                                  // first global position of the job
   const int npos = min(Q.CL, Q.Ds - 1 - pa);                 // positions of the job; loads 0 .. npos
-  const int slo = dir > 0 ? pa : Q.Ds - 1 - (pa + npos);     // lowest stored slice the job touches (entry e = slice - slo)
+  const int slo = dir > 0 ? pa : Q.Ds - 1 - (pa + npos);     // lowest stored slice the job touches
   const int u0 = cu * Q.CW, v0 = cv * Q.CH;                  // first cell of the column (stored coordinates)
   const unsigned ring_addr = (unsigned)(size_t)(c_lds_cptr_t)smem;
   const unsigned pitch_b = (unsigned)(Q.CW + 1) * VB;
+  const int psgn = dir > 0 ? 1 : -1;
+  const int poff = dir > 0 ? -(Q.Os + pa) : (Q.Os + Q.Ds - 2 - pa);  // relative position of global base slice b: psgn * b + poff
+  const int eoff = -Q.Os - slo;                                      // slot-table entry of global slice b: b + eoff
 
-  // ---- set-up (1): control words, tables of the classification fast path
-  if (tid < 32) ctl[tid] = tid == 0 ? 0 : (tid >= 4 && tid < 8) ? (tid - 4 < NL ? tid - 4 : COL_DONE) : (tid >= 8 && tid < 8 + NW ? 0 : COL_DONE);
+  // ---- the job's cell box as coordinate bounds (inclusive), per model axis.  Base cell i0 = min((int)clamp(p, 0, N-1), N-2)
+  // is monotone in p: i0 >= g  <=>  p >= g (g >= 1), i0 < h  <=>  p < h (h <= N-2); at a face of the volume the cell range
+  // is open-ended and the membership bound [lo, hin] of the region takes over.
+  float Lo[3], Hi[3];
+  {
+    const int gu0 = u0 + Q.Ou, gv0 = v0 + Q.Ov, gs0 = slo + Q.Os;  // global index of the first cell / lowest base slice
+    auto below = [](float x) -> float { return __uint_as_float(__float_as_uint(x) - 1u); };  // (x >= 1)
+    Lo[AU] = gu0 > 0 ? fmaxf(P.lo[AU], (float)gu0) : P.lo[AU];
+    Hi[AU] = gu0 + Q.CW <= NU - 2 ? fminf(P.hin[AU], below((float)(gu0 + Q.CW))) : P.hin[AU];
+    Lo[AV] = gv0 > 0 ? fmaxf(P.lo[AV], (float)gv0) : P.lo[AV];
+    Hi[AV] = gv0 + Q.CH <= NV - 2 ? fminf(P.hin[AV], below((float)(gv0 + Q.CH))) : P.hin[AV];
+    Lo[AS] = gs0 > 0 ? fmaxf(P.lo[AS], (float)gs0) : P.lo[AS];
+    Hi[AS] = gs0 + npos <= NS - 2 ? fminf(P.hin[AS], below((float)(gs0 + npos))) : P.hin[AS];
+  }
+  const bool empty_job = !(Lo[0] <= Hi[0] && Lo[1] <= Hi[1] && Lo[2] <= Hi[2]) || npos <= 0;
+
+  // ---- set-up (1): control words, slot table, tables of the classification fast path, histogram
+  if (tid < 32) ctl[tid] = (tid >= 4 && tid < 8) ? (tid - 4 < NL ? tid - 4 : COL_DONE) : (tid >= 8 && tid < 8 + NW ? 0 : (tid >= 8 ? COL_DONE : 0));
+  for (int e = tid; e <= npos; e += NTH) {
+    const int r = dir > 0 ? e : npos - e;  // load index of this slice
+    slot_addr[e] = (int)ring_addr + (r % Q.nslots) * slot_stride;
+  }
+  for (int e = tid; e < 2 * (COL_MAX_CL + 4); e += NTH) hist[e] = 0;  // (hist and hist2 are adjacent)
   if (Q.use_ah)
     for (int e = tid; e < P.sv; e += NTH) ah[e] = smk_ub(P.tf_h[e], 3);
   if (Q.use_occ) {
     uint32_t *occ_w = const_cast<uint32_t *>(occ);
     for (int e = tid; e < P.occ_roww * (TF == 2 ? P.s3g : P.sg); e += NTH) occ_w[e] = P.tf_occ[e];
   }
-  // ---- set-up (2): the pixel box of every position.  A sample whose base cell lies in (column, base slice e) sits in the
-  // real box [u0, u0+CW] x [v0, v0+CH] x [e, e+1] (stretched by half a voxel where it touches a face of the volume: the
-  // membership test admits coordinates down to -0.5 and up to N-0.5 and the clamp folds them into the edge cells); its
-  // pixel is the projection of that point, so the pixels that can hold such a sample lie inside the bounding box of the
-  // eight projected corners.
-  for (int w = tid; w < npos * 8; w += NTH) {
-    const int e = w >> 3, c = w & 7;
-    const int gu0 = u0 + Q.Ou, gv0 = v0 + Q.Ov, gs0 = slo + e + Q.Os;  // global indices
-    const float eps = 0.01f;
-    float xu = (c & 1) ? (gu0 + Q.CW >= NU - 1 ? (float)NU - 0.5f + eps : (float)(gu0 + Q.CW) + eps) : (gu0 <= 0 ? -0.5f - eps : (float)gu0 - eps);
-    float xv = (c & 2) ? (gv0 + Q.CH >= NV - 1 ? (float)NV - 0.5f + eps : (float)(gv0 + Q.CH) + eps) : (gv0 <= 0 ? -0.5f - eps : (float)gv0 - eps);
-    float xs = (c & 4) ? (gs0 + 1 >= NS - 1 ? (float)NS - 0.5f + eps : (float)(gs0 + 1) + eps) : (gs0 <= 0 ? -0.5f - eps : (float)gs0 - eps);
-    float X[3];
-    X[AU] = xu; X[AV] = xv; X[AS] = xs;
-    const float wq = Q.Mw[0] * X[0] + Q.Mw[1] * X[1] + Q.Mw[2] * X[2] + Q.Mw[3];
-    const float xn = Q.Mx[0] * X[0] + Q.Mx[1] * X[1] + Q.Mx[2] * X[2] + Q.Mx[3];
-    const float yn = Q.My[0] * X[0] + Q.My[1] * X[1] + Q.My[2] * X[2] + Q.My[3];
-    const bool bad = !(wq > 1e-12f);
-    const float px = bad ? 0.f : xn / wq, py = bad ? 0.f : yn / wq;
-    // pixels whose centre i + .5 lies in [min, max]
-    float xl = px, xh = px, yl = py, yh = py;
+  // ---- set-up (2): candidate pixels = the bounding box of the job box's eight projected corners (a sample in the box
+  // projects inside their convex hull).  Every thread computes it (wave-uniform arithmetic).
+  int ci0 = 0, ci1 = -1, cj0 = 0, cj1 = -1;
+  if (!empty_job) {
+    float xl = 1e30f, xh = -1e30f, yl = 1e30f, yh = -1e30f;
+    bool bad = false;
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {
-      xl = fminf(xl, __shfl_xor(xl, o)); xh = fmaxf(xh, __shfl_xor(xh, o));
-      yl = fminf(yl, __shfl_xor(yl, o)); yh = fmaxf(yh, __shfl_xor(yh, o));
+    for (int c = 0; c < 8; ++c) {
+      float X[3];
+      const float eps = 0.01f;
+      X[0] = (c & 1) ? Hi[0] + eps : Lo[0] - eps;
+      X[1] = (c & 2) ? Hi[1] + eps : Lo[1] - eps;
+      X[2] = (c & 4) ? Hi[2] + eps : Lo[2] - eps;
+      const float wq = Q.Mw[0] * X[0] + Q.Mw[1] * X[1] + Q.Mw[2] * X[2] + Q.Mw[3];
+      const float xn = Q.Mx[0] * X[0] + Q.Mx[1] * X[1] + Q.Mx[2] * X[2] + Q.Mx[3];
+      const float yn = Q.My[0] * X[0] + Q.My[1] * X[1] + Q.My[2] * X[2] + Q.My[3];
+      bad = bad || !(wq > 1e-12f);
+      const float iw = 1.0f / wq;
+      xl = fminf(xl, xn * iw); xh = fmaxf(xh, xn * iw);
+      yl = fminf(yl, yn * iw); yh = fmaxf(yh, yn * iw);
     }
-    const bool anybad = (__ballot(bad) >> (lane & ~7)) & 0xffull;
-    if (anybad) ctl[0] = 3;
-    if (c == 0) {
+    if (bad) {
+      if (tid == 0) ctl[0] = 3;
+    } else {
+      // pixels whose centre i + .5 lies in [min, max]
       const float lim = 30000.f;
-      scratch[e] = (int)ceilf(fminf(fmaxf(xl - 0.5f - COL_BOX_MARGIN, -lim), lim));
-      scratch[COL_MAX_CL + e] = (int)floorf(fminf(fmaxf(xh - 0.5f + COL_BOX_MARGIN, -lim), lim));
-      scratch[2 * COL_MAX_CL + e] = (int)ceilf(fminf(fmaxf(yl - 0.5f - COL_BOX_MARGIN, -lim), lim));
-      scratch[3 * COL_MAX_CL + e] = (int)floorf(fminf(fmaxf(yh - 0.5f + COL_BOX_MARGIN, -lim), lim));
+      ci0 = max((int)ceilf(fminf(fmaxf(xl - 0.5f - COL_BOX_MARGIN, -lim), lim)), 0);
+      ci1 = min((int)floorf(fminf(fmaxf(xh - 0.5f + COL_BOX_MARGIN, -lim), lim)), P.W - 1);
+      cj0 = max((int)ceilf(fminf(fmaxf(yl - 0.5f - COL_BOX_MARGIN, -lim), lim)), 0);
+      cj1 = min((int)floorf(fminf(fmaxf(yh - 0.5f + COL_BOX_MARGIN, -lim), lim)), P.H - 1);
     }
   }
   __syncthreads();
-  // ---- set-up (3): box origins, monotone in the slice index (so a pixel stays inside the sliding box for ONE run of
-  // positions): the running minimum of the lower bounds from the end the box moves away from; the lattice must cover
-  // every position's bounds from that origin.  One wave per image axis; then the table.
-  if (wave < 2 && npos > 0) {
-    const int *lo = scratch + (wave == 0 ? 0 : 2 * COL_MAX_CL), *hi = scratch + (wave == 0 ? COL_MAX_CL : 3 * COL_MAX_CL);
-    const int L = wave == 0 ? La : Lb;
-    const bool up = lo[npos - 1] >= lo[0];  // the lower bound rises with e: origin(e) = min over e' >= e; else min over e' <= e
-    int carry = 0x7fffffff;
-    bool fits = true;
-    const int nblk = (npos + 63) >> 6;
-    for (int b = 0; b < nblk; ++b) {
-      const int blk = up ? nblk - 1 - b : b;
-      const int e = (blk << 6) + lane;
-      int v = e < npos ? lo[e] : 0x7fffffff;
-      // inclusive scan of min, towards higher lanes (down) or lower lanes (up)
+  // base slice (global) and clamped coordinate of plane q on a ray: exactly smk_lin_clamp's (xc, i0) of the principal axis
+  auto base_slice = [&](const float (&A)[3], const float (&B)[3], int q, float &sc_out) -> int {
+    const float s = __fmaf_rn((float)q, B[AS], A[AS]);
+    sc_out = smk_clampf(s, 0.0f, (float)(NS - 1));
+    return min((int)sc_out, NS - 2);
+  };
+  // ---- set-up (3): the rays.  A thread per candidate pixel (rows of 32), the plane interval of its ray in the job box.
+  {
+    const int cw = ci1 - ci0 + 1, chh = cj1 - cj0 + 1;
+    for (int jj = tid >> 5; jj < chh; jj += NTH / 32) {
+      for (int i0 = 0; i0 < cw; i0 += 32) {
+        const int ii = i0 + (tid & 31);
+        bool have = false;
+        int m_in = 0, m_out = -1;
+        const int i = ci0 + ii, j = cj0 + jj;
+        float A[3], B[3];
+        if (ii < cw) {
+          const float px = __fmaf_rn((float)i + 0.5f, rc.pxs, rc.pxl);
+          const float py = __fmaf_rn((float)j + 0.5f, rc.pys, rc.pyl);
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            A[a] = __fmaf_rn(px, rc.Ax[a], __fmaf_rn(py, rc.Ay[a], rc.Ac[a]));
+            B[a] = __fmaf_rn(px, rc.Bx[a], __fmaf_rn(py, rc.By[a], rc.Bc[a]));
+          }
+          // bracket: real-valued plane range per axis, a plane of slack (the quotient is off by far less); the exact test at the ends decides
+          float tin = 0.0f, tout = (float)(rc.nplanes - 1);
+          bool none = false;
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            if (fabsf(B[a]) > 1e-20f) {
+              const float inv = 1.0f / B[a];
+              const float t1 = (Lo[a] - A[a]) * inv, t2 = (Hi[a] - A[a]) * inv;
+              tin = fmaxf(tin, fminf(t1, t2) - 1.0f);
+              tout = fminf(tout, fmaxf(t1, t2) + 1.0f);
+            } else if (!(A[a] >= Lo[a] && A[a] <= Hi[a])) {
+              none = true;
+            }
+          }
+          if (!none && tin <= tout) {
+            int qa = (int)floorf(fmaxf(tin, 0.0f)), qb = (int)ceilf(fminf(tout, (float)(rc.nplanes - 1)));
+            auto in = [&](int q) -> bool {
+              const float qf = (float)q;
+              const float p0 = __fmaf_rn(qf, B[0], A[0]), p1 = __fmaf_rn(qf, B[1], A[1]), p2 = __fmaf_rn(qf, B[2], A[2]);
+              return ((int)(smk_clampf(p0, Lo[0], Hi[0]) == p0) & (int)(smk_clampf(p1, Lo[1], Hi[1]) == p1) & (int)(smk_clampf(p2, Lo[2], Hi[2]) == p2)) != 0;
+            };
+            // the ends move inwards until they are inside (a few steps: the slack is two planes; a ray that only grazes
+            // the box ends empty).  Coordinates are monotone in q, so everything between two inside planes is inside.
+#pragma unroll 1
+            for (int k = 0; k < 8 && qa <= qb && !in(qa); ++k) ++qa;
+#pragma unroll 1
+            for (int k = 0; k < 8 && qa <= qb && !in(qb); ++k) --qb;
+            if (qa <= qb && (in(qa) & in(qb))) {
+              have = true;
+              m_in = qa;
+              m_out = qb;
+            }
+          }
+        }
+        // append to the unsorted list, count its entry position
+        const unsigned long long bal = __ballot(have);
+        if (bal) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&ctl[3], (int)__popcll(bal));
+          base = __builtin_amdgcn_readfirstlane(base);
+          if (have) {
+            const int idx = base + (int)__popcll(bal & ((1ull << lane) - 1ull));
+            float sc;
+            const int ep = psgn * base_slice(A, B, m_in, sc) + poff;  // in [0, npos)
+            if (idx < COL_MAX_RAYS) {
+              tmp[idx] = make_uint4((unsigned)i | ((unsigned)j << 16), (unsigned)m_in, (unsigned)m_out, (unsigned)ep);
+              atomicAdd(&hist[min(max(ep, 0), COL_MAX_CL)], 1);
+              const int xp = psgn * base_slice(A, B, m_out, sc) + poff;
+              atomicAdd(&hist2[min(max(xp, 0), COL_MAX_CL)], 1);
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int nrays = min(ctl[3], COL_MAX_RAYS);
+  if (tid == 0 && ctl[3] > COL_MAX_RAYS) ctl[0] = 3;  // more rays than the list holds: reported, the frame is rendered another way
+  // ---- set-up (4): order by entry position (counting sort: exclusive prefix of the histogram, then scatter)
+  if (wave == 0) {
+    int carry = 0;
+    for (int b0 = 0; b0 <= COL_MAX_CL; b0 += 64) {
+      const int e = b0 + lane;
+      const int v = e <= COL_MAX_CL ? hist[e] : 0;
+      int incl = v;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
-        const int t = up ? __shfl_down(v, o) : __shfl_up(v, o);
-        const bool ok = up ? lane + o < 64 : lane >= o;
-        if (ok) v = min(v, t);
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
       }
-      v = min(v, carry);
-      carry = __builtin_amdgcn_readlane(v, up ? 0 : 63);
-      if (e < npos) {
-        if (hi[e] - v + 1 > L) fits = false;
-        // (kept beside the bounds until both axes are done)
-        scratch[(wave == 0 ? 4 : 5) * COL_MAX_CL + e] = v;
-      }
+      if (e <= COL_MAX_CL) hist[e] = carry + incl - v;
+      carry += __builtin_amdgcn_readlane(incl, 63);
     }
-    if (__any(!fits) && lane == 0) ctl[0] = 3;
+    // rays inside at position T = entered at <= T minus left before T: all of them want a lane at once
+    int carry_in = 0, carry_out = 0, worst = 0;
+    for (int b0 = 0; b0 <= COL_MAX_CL; b0 += 64) {
+      const int e = b0 + lane;
+      const int nin = e < COL_MAX_CL ? hist[e + 1] : nrays;           // entries at positions <= e (exclusive prefix of e + 1)
+      const int vo = e <= COL_MAX_CL ? hist2[e] : 0;
+      int incl = vo;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+      }
+      const int nout = carry_out + incl - vo;                         // exits at positions < e
+      int alive = e <= COL_MAX_CL ? nin - nout : 0;
+      for (int o = 32; o > 0; o >>= 1) alive = max(alive, __shfl_xor(alive, o));
+      worst = max(worst, alive);
+      carry_out += __builtin_amdgcn_readlane(incl, 63);
+      (void)carry_in;
+    }
+    if (lane == 0 && worst > NW * 64) ctl[0] = 3;  // more rays inside at once than lanes: reported before anything is streamed
   }
   __syncthreads();
-  for (int e = tid; e <= npos; e += NTH) {
-    const int r = dir > 0 ? e : npos - e;  // load index of this slice
-    ColEnt ent;
-    ent.addr = (int)ring_addr + (r % Q.nslots) * slot_stride;
-    ent.box = 0;
-    if (e < npos) ent.box = (scratch[4 * COL_MAX_CL + e] & 0xffff) | (scratch[5 * COL_MAX_CL + e] << 16);
-    tab[e] = ent;
+  for (int n = tid; n < nrays; n += NTH) {
+    const uint4 t = tmp[n];
+    const int at = atomicAdd(&hist[min(max((int)t.w, 0), COL_MAX_CL)], 1);
+    const unsigned cnt = t.z - t.y + 1u;
+    if (cnt > 4095u || t.y >= (1u << 20)) ctl[0] = 5;
+    list[at] = make_uint2(t.x, t.y | (cnt << 20));
+    epos[at] = (unsigned char)t.w;
   }
-  __syncthreads();  // tables visible; the ring's memory is free from here on.  LAST workgroup barrier before the end
+  if (tid == 0) ctl[2] = nrays;
+  __syncthreads();  // list visible; the ring's memory is free from here on.  LAST workgroup barrier before the end
   const bool failed_setup = ctl[0] != 0;
+  const unsigned t_setup = (unsigned)__builtin_amdgcn_s_memrealtime();
 
   // developer statistics, wave-scalar
-  unsigned n_samples = 0, n_visible = 0, n_segments = 0;
+  unsigned n_samples = 0, n_visible = 0, n_segments = 0, n_iters = 0, n_act = 0, n_swit = 0, n_swl = 0;
 
-  if (!failed_setup && npos > 0) {
+  if (!failed_setup && nrays > 0) {
     if (is_loader) {
       // ================================ loader wave ============================================
       // Loads r = 0 .. npos in marching order, mine are r = lid, lid + NL, ...; the slot of r is r % nslots and may be
-      // rewritten once every consumer is past position r - nslots.  A slice is n_ch whole-KiB LDS-DMA instructions from
-      // ONE contiguous run of memory (the last one with fewer lanes), the same count for every slice, so the in-order
-      // vmcnt tells which slices have landed.
+      // rewritten once every consumer is past position r - nslots AND no ray still to be taken enters before it.  A slice
+      // is n_ch whole-KiB LDS-DMA instructions from ONE contiguous run of memory (the last one with fewer lanes), the same
+      // count for every slice, so the in-order vmcnt tells which slices have landed.
       __builtin_amdgcn_s_setprio(3);
       const int lid = wave - NW;
       const char *col_base = Q.lay + ((size_t)(cv * Q.ncu + cu) * Q.Ds) * (size_t)Q.slice_bytes;
@@ -300,11 +421,20 @@ __global__ __launch_bounds__((NW + NL) * 64) void smk_k_cols(const RenderParams 
       auto poll_progress = [&]() -> int {
         int v = COL_DONE;
         if (lane < 16) v = col_raw_lds_b32(&ctl[8 + lane]);
+        if (lane == 16) {  // the first position of the next ray nobody has taken yet
+          const int head = col_raw_lds_b32(&ctl[1]);
+          if (head < nrays) {
+            const unsigned a = (unsigned)(size_t)(c_lds_cptr_t)(epos + head);
+            unsigned b;
+            asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(b) : "v"(a) : "memory");
+            v = (int)b;
+          }
+        }
         v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
         v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
         v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
         v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
-        return __builtin_amdgcn_readlane(v, 0);
+        return min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16));
       };
       unsigned keep_m0;
       unsigned n_loaded = 0;
@@ -320,7 +450,7 @@ __global__ __launch_bounds__((NW + NL) * 64) void smk_k_cols(const RenderParams 
           const char *src = col_base + (size_t)sl * (size_t)Q.slice_bytes;
           unsigned dst = ring_addr + (unsigned)((r % Q.nslots) * slot_stride);
           int k = 0;
-          // four whole instructions per statement: M0 steps through their LDS images, the source by scalar adds
+          // four whole instructions per statement: M0 steps through their LDS images
           for (; k + 4 < Q.n_ch; k += 4) {
             asm volatile("s_mov_b32 %[km], m0\n\ts_mov_b32 m0, %[dst]\n\ts_nop 0\n\t"
                          "global_load_lds_dwordx4 %[v0], %[src]\n\ts_add_u32 m0, m0, 0x400\n\t"
@@ -374,156 +504,117 @@ __global__ __launch_bounds__((NW + NL) * 64) void smk_k_cols(const RenderParams 
       if (Q.counts && lane == 0 && n_loaded) atomicAdd(&Q.counts[2], (unsigned long long)n_loaded);
     } else {
       // ================================ consumer waves ==========================================
-      const smk_raycoef &rc = P.rc;
-      const int la = 8 * (wave % WA) + (lane & 7);
-      const int psgn = dir > 0 ? 1 : -1;
-      // relative position of global base slice b: psgn * b + poff
-      const int poff = dir > 0 ? -(Q.Os + pa) : (Q.Os + Q.Ds - 2 - pa);
-      const int eoff = -Q.Os - slo;  // table entry of global slice b: b + eoff
-      ColRay ray[R];
+      // (the 18 ray coefficients are wanted every time a lane takes a ray; as scalars they do not fit beside the loop's
+      //  own -- the compiler reloaded them from the kernel arguments each time: kept in vector registers instead)
+      float kAc[3], kAx[3], kAy[3], kBc[3], kBx[3], kBy[3], kps[4];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        asm volatile("v_mov_b32 %0, %1" : "=v"(kAc[a]) : "s"(rc.Ac[a]));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(kAx[a]) : "s"(rc.Ax[a]));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(kAy[a]) : "s"(rc.Ay[a]));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(kBc[a]) : "s"(rc.Bc[a]));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(kBx[a]) : "s"(rc.Bx[a]));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(kBy[a]) : "s"(rc.By[a]));
+      }
+      asm volatile("v_mov_b32 %0, %1" : "=v"(kps[0]) : "s"(rc.pxs));
+      asm volatile("v_mov_b32 %0, %1" : "=v"(kps[1]) : "s"(rc.pxl));
+      asm volatile("v_mov_b32 %0, %1" : "=v"(kps[2]) : "s"(rc.pys));
+      asm volatile("v_mov_b32 %0, %1" : "=v"(kps[3]) : "s"(rc.pyl));
+      ColRay y;
+      y.C0 = y.C1 = y.C2 = y.C3 = 0.f;
+      y.i = y.j = 0;
+      y.m = 0;
+      y.m_out = -1;
+      y.sc = 0.f;
+      y.bi = 0;
+      y.pb = COL_DONE;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) y.A[a] = y.B[a] = 0.f;
+      bool exhausted = false;  // the list has no ray left for this lane
       auto landed_all = [&]() -> int {
         int4 v;
         const unsigned a = (unsigned)(size_t)(c_lds_cptr_t)(ctl + 4);
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
         return min(min(v.x, v.y), min(v.z, v.w));
       };
-      // base slice (global) and clamped coordinate of plane q on a ray: exactly smk_lin_clamp's (xc, i0) of the principal axis
-      auto base_slice = [&](const ColRay &y, int q, float &sc_out) -> int {
-        const float s = __fmaf_rn((float)q, y.B[AS], y.A[AS]);
-        sc_out = smk_clampf(s, 0.0f, (float)(NS - 1));
-        return min((int)sc_out, NS - 2);
-      };
-      auto in_box = [&](int i, int j, int box) -> bool {
-        const int a0 = (int)(short)(box & 0xffff), b0 = box >> 16;
-        return (unsigned)(i - a0) < (unsigned)La && (unsigned)(j - b0) < (unsigned)Lb;
-      };
       // a ray's partial composite for this job -> layers[key][pixel], key = the job's place along the ray
-      auto flush = [&](ColRay &y) {
+      auto flush = [&]() {
         if (y.C0 != 0.f || y.C1 != 0.f || y.C2 != 0.f || y.C3 != 0.f) {
           const int key = (y.B[AU] >= 0.f ? cu : Q.ncu - 1 - cu) + (y.B[AV] >= 0.f ? cv : Q.ncv - 1 - cv) + ck;
           const size_t pix = (size_t)y.j * P.W + y.i;
           Q.layers[(size_t)key * ((size_t)P.W * P.H) + pix] = make_float4(y.C0, y.C1, y.C2, y.C3);
           atomicOr(&Q.masks[pix * Q.mask_words + (key >> 6)], 1ull << (key & 63));
-          n_segments += 1;  // (per-lane count folded below)
+          n_segments += 1;
         }
         y.C0 = y.C1 = y.C2 = y.C3 = 0.f;
       };
-      // The lane's slot takes the pixel the sliding box holds for it from position p on; the ray's first sample at a
-      // position >= p is found, and so on through pixels that have none inside their stay.  Sets pb = COL_DONE when the
-      // job's positions are exhausted.
-      auto take_next = [&](ColRay &y, int lb, int p) {
-        y.pb = COL_DONE;
-#pragma unroll 1
-        for (int guard = 0; guard < 64; ++guard) {
-          if (p >= npos) return;
-          // table entry of position p: e = dir > 0 ? p : npos - 1 - p
-          const int e0 = dir > 0 ? p : npos - 1 - p;
-          const int box = tab[e0].box;
-          const int a0 = (int)(short)(box & 0xffff), b0 = box >> 16;
-          int di = (la - a0) % La, dj = (lb - b0) % Lb;
-          di += di < 0 ? La : 0;
-          dj += dj < 0 ? Lb : 0;
-          const int i = a0 + di, j = b0 + dj;
-          bool advanced = false;
-          if (i >= 0 && i < P.W && j >= 0 && j < P.H) {
-            y.i = i;
-            y.j = j;
-            const float px = __fmaf_rn((float)i + 0.5f, rc.pxs, rc.pxl);
-            const float py = __fmaf_rn((float)j + 0.5f, rc.pys, rc.pyl);
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-              y.A[a] = __fmaf_rn(px, rc.Ax[a], __fmaf_rn(py, rc.Ay[a], rc.Ac[a]));
-              y.B[a] = __fmaf_rn(px, rc.Bx[a], __fmaf_rn(py, rc.By[a], rc.Bc[a]));
-            }
-            // first plane whose sample is at a position >= p and on the inner side of the face the rays enter through
-            // (s monotone in the plane index; the estimate is off by far less than a plane, the exact evaluation decides)
-            const int bneed = dir > 0 ? (p - poff) : (poff - p);  // global base slice of position p
-            float target;
-            if (dir > 0) target = bneed > 0 ? fmaxf((float)bneed, P.lo[AS]) : P.lo[AS];
-            else target = bneed < NS - 2 ? fminf((float)(bneed + 1), P.hin[AS]) : P.hin[AS];
-            const float inv = 1.0f / y.B[AS];
-            const float t = (target - y.A[AS]) * inv;
-            auto ok = [&](int q) -> bool {
-              float sc;
-              const float s = __fmaf_rn((float)q, y.B[AS], y.A[AS]);
-              const int b = base_slice(y, q, sc);
-              const bool inner = dir > 0 ? s >= P.lo[AS] : s <= P.hin[AS];
-              return inner && (psgn * b + poff) >= p;
-            };
-            int q = (int)fminf(fmaxf(ceilf(t), 0.0f), (float)rc.nplanes);
-            bool found = false;
-#pragma unroll 1
-            for (int k = 0; k < 4; ++k) {  // down while the plane before is also ok
-              if (q > 0 && ok(q - 1)) --q; else break;
-            }
-#pragma unroll 1
-            for (int k = 0; k < 6; ++k) {
-              if (q >= rc.nplanes) break;
-              if (ok(q)) { found = true; break; }
-              ++q;
-            }
-            if (found) {
-              float sc;
-              const int b = base_slice(y, q, sc);
-              const float s = __fmaf_rn((float)q, y.B[AS], y.A[AS]);
-              const bool dead = dir > 0 ? s > P.hin[AS] : s < P.lo[AS];  // beyond the face the rays leave through: nothing more, ever
-              const int pbn = psgn * b + poff;
-              if (!dead && pbn < npos) {
-                const int e1 = dir > 0 ? pbn : npos - 1 - pbn;
-                if (in_box(i, j, tab[e1].box)) {
-                  y.m = q;
-                  y.pb = pbn;
-                  y.sc = sc;
-                  y.bi = b;
-                  return;
-                }
-                p = pbn;  // the box has moved on before this ray's next sample: that position's pixel is another one
-                advanced = true;
-              }
-              // (dead, or the next sample lies behind the job: the slot may still get another pixel before the job ends)
-            } else if (q < rc.nplanes) {
-              ctl[0] = 4;  // the bracket did not close: reported, never silent
-              return;
-            }
+      int pos = 0, have = 0, since_take = 0;
+      bool first_turn = true;
+      for (;;) {
+        bool took = false;
+        // ---- lanes without a ray take the next ones of the list (one counter bump per wave)
+        {
+          const bool want = y.pb >= COL_DONE && !exhausted;
+          unsigned long long bal = __ballot(want);
+          // (a take costs the wave ~60 vector instructions whatever the number of lanes: free lanes wait for company
+          //  unless nobody works, or they have waited take_wait turns)
+          const int nfree = (int)__popcll(bal);
+          // (never while the wave is about to wait for data: the ray at the list's head may be what holds the ring's tail)
+          if (bal && nfree < Q.take_min && since_take < Q.take_wait && __any(y.pb < COL_DONE) && have >= min(pos + 2 + Q.wstep, npos + 1)) {
+            bal = 0;
+            ++since_take;
           }
-          if (!advanced) {
-            // nothing to do for this pixel (outside the image, or its ray has no sample left): first position > p at
-            // which the box no longer holds it (the origins are monotone: one run of positions per pixel)
-            int lo = p, hi = npos;
-#pragma unroll 1
-            while (hi - lo > 1) {
-              const int mid = (lo + hi) >> 1;
-              const int em = dir > 0 ? mid : npos - 1 - mid;
-              if (in_box(i, j, tab[em].box)) lo = mid; else hi = mid;
+          if (bal) {
+            since_take = 0;
+            took = true;
+            // the word this wave has published must cover whatever it takes: every ray from the head on enters at or
+            // behind the head's entry (sorted list), so that entry goes into the word BEFORE the head moves -- a loader
+            // that sees the new head also sees the lowered word
+            {
+              const int h0 = col_lds_ld(&ctl[1]);
+              if (h0 < nrays) {
+                const int e0 = (int)epos[h0];
+                if (e0 < pos) {
+                  pos = e0;
+                  if (lane == 0) col_lds_st(&ctl[8 + wave], pos);
+                }
+              }
             }
-            p = hi;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&ctl[1], (int)__popcll(bal));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (want) {
+              const int n = base + (int)__popcll(bal & ((1ull << lane) - 1ull));
+              if (n < nrays) {
+                const uint2 e = list[n];
+                y.i = (int)(e.x & 0xffffu);
+                y.j = (int)(e.x >> 16);
+                y.m = (int)(e.y & 0xfffffu);
+                y.m_out = y.m + (int)(e.y >> 20) - 1;
+                const float px = __fmaf_rn((float)y.i + 0.5f, kps[0], kps[1]);
+                const float py = __fmaf_rn((float)y.j + 0.5f, kps[2], kps[3]);
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                  y.A[a] = __fmaf_rn(px, kAx[a], __fmaf_rn(py, kAy[a], kAc[a]));
+                  y.B[a] = __fmaf_rn(px, kBx[a], __fmaf_rn(py, kBy[a], kBc[a]));
+                }
+                y.bi = base_slice(y.A, y.B, y.m, y.sc);
+                y.pb = psgn * y.bi + poff;
+              } else {
+                exhausted = true;
+              }
+            }
+            if (Q.counts) {
+              n_swit += 1;
+              n_swl += (unsigned)__popcll(bal);
+            }
           }
         }
-        ctl[0] = 4;
-      };
-
-      int lbr[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        lbr[r] = r * Lb1 + 8 * (wave / WA) + (lane >> 3);
-        ray[r].C0 = ray[r].C1 = ray[r].C2 = ray[r].C3 = 0.f;
-        ray[r].i = ray[r].j = 0;
-        ray[r].m = 0;
-        ray[r].sc = 0.f;
-        ray[r].bi = 0;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) ray[r].A[a] = ray[r].B[a] = 0.f;
-        take_next(ray[r], lbr[r], 0);
-      }
-      int pos = 0, have = 0;
-      for (;;) {
-        int pmin = COL_DONE;
-#pragma unroll
-        for (int r = 0; r < R; ++r) pmin = min(pmin, ray[r].pb);
-        if (!__any(pmin < COL_DONE)) break;
-        // wait until the slowest lane's two slices (+ wstep more) have landed
-        {
-          const int plo = col_wave_min(pmin);
+        if (!__any(y.pb < COL_DONE)) break;  // (a lane without a ray here is exhausted: the list is sorted, nothing is left)
+        // progress = position of the slowest lane (known from the release below unless rays were taken just now)
+        if (took || first_turn) {
+          first_turn = false;
+          const int plo = col_wave_min(y.pb);
           if (plo != pos) {
             pos = plo;
             if (lane == 0) col_lds_st(&ctl[8 + wave], pos);
@@ -537,8 +628,8 @@ __global__ __launch_bounds__((NW + NL) * 64) void smk_k_cols(const RenderParams 
             if (spins > (1 << 22) || flagged) {
               if (!flagged) col_lds_st(&ctl[0], 1);
               have = 0x3ffffff0;
-#pragma unroll
-              for (int r = 0; r < R; ++r) ray[r].pb = COL_DONE;
+              y.pb = COL_DONE;
+              exhausted = true;
               break;
             }
             __builtin_amdgcn_s_sleep(2);
@@ -547,222 +638,191 @@ __global__ __launch_bounds__((NW + NL) * 64) void smk_k_cols(const RenderParams 
           have = __builtin_amdgcn_readfirstlane(have);
         }
         asm volatile("" ::: "memory");
-        // ---- part A (per ray): where the sample is, whether it is this job's, its eight corners; then where the NEXT one is
-        bool act[R], work[R], sw[R];
-        float fx[R], fy[R], fz[R], nsc[R];
-        int nbi[R], npb[R];
-        typename std::conditional<DT == 0, c_v2u, c_v4f>::type rq[R][8];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          ColRay &y = ray[r];
-          act[r] = y.pb < COL_DONE && y.pb + 2 <= have;
-          work[r] = false;
-          sw[r] = false;
-          fx[r] = fy[r] = fz[r] = 0.f;
-          nsc[r] = y.sc;
-          nbi[r] = y.bi;
-          npb[r] = y.pb;
-          if (act[r]) {
-            const float mf = (float)y.m;
-            const float p0 = __fmaf_rn(mf, y.B[0], y.A[0]), p1 = __fmaf_rn(mf, y.B[1], y.A[1]), p2 = __fmaf_rn(mf, y.B[2], y.A[2]);
-            // membership: the gather kernel's predicate (lo <= p <= hin on every axis)
-            const bool inside = ((int)(smk_clampf(p0, P.lo[0], P.hin[0]) == p0) & (int)(smk_clampf(p1, P.lo[1], P.hin[1]) == p1) &
-                                 (int)(smk_clampf(p2, P.lo[2], P.hin[2]) == p2)) != 0;
-            int x0 = 0, x1, y0 = 0, y1, z0 = 0, z1;
-            if constexpr (AS != 0) smk_lin_clamp(p0, P.N[0], x0, x1, fx[r]);
-            else { x0 = y.bi; fx[r] = y.sc - (float)y.bi; }
-            if constexpr (AS != 1) smk_lin_clamp(p1, P.N[1], y0, y1, fy[r]);
-            else { y0 = y.bi; fy[r] = y.sc - (float)y.bi; }
-            if constexpr (AS != 2) smk_lin_clamp(p2, P.N[2], z0, z1, fz[r]);
-            else { z0 = y.bi; fz[r] = y.sc - (float)y.bi; }
-            (void)x1; (void)y1; (void)z1;
-            const int iu = (AU == 0 ? x0 : y0) - Q.Ou - u0, iv = (AV == 1 ? y0 : z0) - Q.Ov - v0;  // cell inside the column
-            work[r] = inside && (unsigned)iu < (unsigned)Q.CW && (unsigned)iv < (unsigned)Q.CH;
-            const ColEnt *te = tab + (y.bi + eoff);
-            if (work[r]) {
-              const unsigned off = __umul24((unsigned)iv, pitch_b) + (unsigned)iu * VB;
-              const unsigned a0 = (unsigned)te[0].addr + off, b0 = (unsigned)te[1].addr + off;
-              col_read8(a0, a0 + pitch_b, b0, b0 + pitch_b, rq[r]);
-            }
-            // the next sample of this ray: its position, and whether the box still holds the pixel there
-            const int mn = y.m + 1;
-            if (mn < rc.nplanes) {
-              nbi[r] = base_slice(y, mn, nsc[r]);
-              npb[r] = psgn * nbi[r] + poff;
-              if (npb[r] >= npos) sw[r] = true;  // behind the job (or the clamped end of the volume)
-              else sw[r] = !in_box(y.i, y.j, tab[nbi[r] + eoff].box);
-            } else {
-              sw[r] = true;
-            }
+        // ---- part A: where the sample is, its eight corners; then where the next one is
+        const bool act = y.pb < COL_DONE && y.pb + 2 <= have;
+        float fx = 0.f, fy = 0.f, fz = 0.f, nsc = y.sc;
+        int nbi = y.bi, npb = y.pb;
+        bool last = false;
+        typename std::conditional<DT == 0, c_v2u, c_v4f>::type rq[8];
+        if (act) {
+          const float mf = (float)y.m;
+          int x0 = 0, x1, y0 = 0, y1, z0 = 0, z1;
+          if constexpr (AS != 0) smk_lin_clamp(__fmaf_rn(mf, y.B[0], y.A[0]), P.N[0], x0, x1, fx);
+          else { x0 = y.bi; fx = y.sc - (float)y.bi; }
+          if constexpr (AS != 1) smk_lin_clamp(__fmaf_rn(mf, y.B[1], y.A[1]), P.N[1], y0, y1, fy);
+          else { y0 = y.bi; fy = y.sc - (float)y.bi; }
+          if constexpr (AS != 2) smk_lin_clamp(__fmaf_rn(mf, y.B[2], y.A[2]), P.N[2], z0, z1, fz);
+          else { z0 = y.bi; fz = y.sc - (float)y.bi; }
+          (void)x1; (void)y1; (void)z1;
+          const int iu = (AU == 0 ? x0 : y0) - Q.Ou - u0, iv = (AV == 1 ? y0 : z0) - Q.Ov - v0;  // cell inside the column
+          const int *te = slot_addr + (y.bi + eoff);
+          const unsigned off = __umul24((unsigned)iv, pitch_b) + (unsigned)iu * VB;
+          const unsigned a0 = (unsigned)te[0] + off, b0 = (unsigned)te[1] + off;
+          col_read8(a0, a0 + pitch_b, b0, b0 + pitch_b, rq);
+          if (y.m < y.m_out) {
+            nbi = base_slice(y.A, y.B, y.m + 1, nsc);
+            npb = psgn * nbi + poff;
+          } else {
+            last = true;
+            npb = COL_DONE;
           }
         }
-        // everything this iteration needs of the ring is in registers: release the slots now.  A lane that changes rays
-        // below may come back to the position behind the sample it has just taken.
+        // everything this iteration needs of the ring is in registers: release the slots now (a lane whose ray ends takes
+        // its next one from the list's head, which the loaders count in themselves)
         {
-          int pn = COL_DONE;
-#pragma unroll
-          for (int r = 0; r < R; ++r) pn = min(pn, act[r] ? (sw[r] ? ray[r].pb + 1 : npb[r]) : ray[r].pb);
-          const int plo = col_wave_min(pn);
+          const int plo = col_wave_min(npb);
           if (plo != pos && plo < COL_DONE) {
             pos = plo;
             if (lane == 0) col_lds_st(&ctl[8 + wave], pos);
           }
         }
-        // ---- part B (per ray): interpolate, classify, shade, blend -- the gather kernel's operations in its order
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          ColRay &y = ray[r];
-          if (Q.counts) n_samples += (unsigned)__popcll(__ballot(work[r]));
-          bool hit = false;
-          if (work[r]) {
-            const float fxr = fx[r], fyr = fy[r], fzr = fz[r];
+        // ---- part B: interpolate, classify, shade, blend -- the gather kernel's operations in its order
+        bool hit = false;
+        if (act) {
 #define QI(dx, dy, dz) (PERM == 0 ? ((dz) * 4 + (dy) * 2 + (dx)) : PERM == 1 ? ((dy) * 4 + (dz) * 2 + (dx)) : ((dx) * 4 + (dz) * 2 + (dy)))
 #define TRI(E)                                                                                                             \
-  smk_lerp(smk_lerp(smk_lerp(E(0, 0, 0), E(1, 0, 0), fxr), smk_lerp(E(0, 1, 0), E(1, 1, 0), fxr), fyr),                    \
-           smk_lerp(smk_lerp(E(0, 0, 1), E(1, 0, 1), fxr), smk_lerp(E(0, 1, 1), E(1, 1, 1), fxr), fyr), fzr)
-            float ch0, ch1 = 0.f, ch2 = 0.f, ch3 = 0.f;
-            const bool lazy_h = (TF == 1 && Q.fast_tf) || (TF == 2 && Q.use_occ);
-            auto tri_h = [&]() -> float {
-              if constexpr (DT == 0) {
-#define E2(dx, dy, dz) smk_ub(rq[r][QI(dx, dy, dz)].x, 2)
-                return TRI(E2) * SMK_INV255;
+  smk_lerp(smk_lerp(smk_lerp(E(0, 0, 0), E(1, 0, 0), fx), smk_lerp(E(0, 1, 0), E(1, 1, 0), fx), fy),                       \
+           smk_lerp(smk_lerp(E(0, 0, 1), E(1, 0, 1), fx), smk_lerp(E(0, 1, 1), E(1, 1, 1), fx), fy), fz)
+          float ch0, ch1 = 0.f, ch2 = 0.f, ch3 = 0.f;
+          const bool lazy_h = (TF == 1 && Q.fast_tf) || (TF == 2 && Q.use_occ);
+          auto tri_h = [&]() -> float {
+            if constexpr (DT == 0) {
+#define E2(dx, dy, dz) smk_ub(rq[QI(dx, dy, dz)].x, 2)
+              return TRI(E2) * SMK_INV255;
 #undef E2
-              } else {
-#define E2(dx, dy, dz) rq[r][QI(dx, dy, dz)].z
-                return TRI(E2);
+            } else {
+#define E2(dx, dy, dz) rq[QI(dx, dy, dz)].z
+              return TRI(E2);
 #undef E2
-              }
-            };
-            if constexpr (DT == 1) {
-#define E0(dx, dy, dz) rq[r][QI(dx, dy, dz)].x
-#define E1(dx, dy, dz) rq[r][QI(dx, dy, dz)].y
-              ch0 = TRI(E0);
-              if (TF != 0 || SH != 0) ch1 = TRI(E1);
-              if ((TF == 2 || (TF == 1 && P.third_axis)) && !lazy_h) ch2 = tri_h();
+            }
+          };
+          if constexpr (DT == 1) {
+#define E0(dx, dy, dz) rq[QI(dx, dy, dz)].x
+#define E1(dx, dy, dz) rq[QI(dx, dy, dz)].y
+            ch0 = TRI(E0);
+            if (TF != 0 || SH != 0) ch1 = TRI(E1);
+            if ((TF == 2 || (TF == 1 && P.third_axis)) && !lazy_h) ch2 = tri_h();
 #undef E1
 #undef E0
-            } else {
-#define E0(dx, dy, dz) smk_ub(rq[r][QI(dx, dy, dz)].x, 0)
-#define E1(dx, dy, dz) smk_ub(rq[r][QI(dx, dy, dz)].x, 1)
-#define E3(dx, dy, dz) smk_ub(rq[r][QI(dx, dy, dz)].x, 3)
-              ch0 = TRI(E0) * SMK_INV255;
-              if (TF != 0 || SH != 0) ch1 = TRI(E1) * SMK_INV255;
-              if ((TF == 2 || (TF == 1 && P.third_axis)) && !lazy_h) {
-                ch2 = tri_h();
-                if (P.nelts == 4) ch3 = TRI(E3) * SMK_INV255;
-              }
+          } else {
+#define E0(dx, dy, dz) smk_ub(rq[QI(dx, dy, dz)].x, 0)
+#define E1(dx, dy, dz) smk_ub(rq[QI(dx, dy, dz)].x, 1)
+#define E3(dx, dy, dz) smk_ub(rq[QI(dx, dy, dz)].x, 3)
+            ch0 = TRI(E0) * SMK_INV255;
+            if (TF != 0 || SH != 0) ch1 = TRI(E1) * SMK_INV255;
+            if ((TF == 2 || (TF == 1 && P.third_axis)) && !lazy_h) {
+              ch2 = tri_h();
+              if (P.nelts == 4) ch3 = TRI(E3) * SMK_INV255;
+            }
 #undef E3
 #undef E1
 #undef E0
-            }
-            float4 col;
-            ColTexel4 tx4 = {0, 0, 0, 0, 0.f, 0.f};
-            if (TF == 1 && Q.fast_tf) {
-              int s0, s1, t0, t1;
-              float fs, ft;
-              smk_lin_clamp(__fmaf_rn(ch0, (float)P.sv, -0.5f), P.sv, s0, s1, fs);
-              smk_lin_clamp(__fmaf_rn(ch1, (float)P.sg, -0.5f), P.sg, t0, t1, ft);
-              bool maybe = true;
-              if (Q.use_occ) maybe = (occ[__mul24(t0, P.occ_roww) + (s0 >> 5)] >> (s0 & 31)) & 1u;
-              col.w = 0.0f;
-              if (maybe) {
-                tx4 = col_tex2d_fetch(P.tf_vg, P.sv, s0, t0, fs, ft);
-                col.w = col_tex_chan(tx4, 3);
-                if (Q.use_ah) {
-                  ch2 = tri_h();
-                  int h0, h1;
-                  float fh;
-                  smk_lin_clamp(__fmaf_rn(ch2, (float)P.sv, -0.5f), P.sv, h0, h1, fh);
-                  col.w *= smk_lerp(ah[h0], ah[h0 + 1], fh) * SMK_INV255;
-                }
-                col.w = smk_sat(col.w);
-              }
-              hit = col.w != 0.0f;
-            } else if (TF == 2 && Q.use_occ) {
-              int s0, s1, t0, t1;
-              float fs, ft;
-              smk_lin_clamp(__fmaf_rn(ch0, (float)P.s3v, -0.5f), P.s3v, s0, s1, fs);
-              smk_lin_clamp(__fmaf_rn(ch1, (float)P.s3g, -0.5f), P.s3g, t0, t1, ft);
-              col.w = 0.0f;
-              hit = false;
-              if ((occ[__mul24(t0, P.occ_roww) + (s0 >> 5)] >> (s0 & 31)) & 1u) {
+          }
+          float4 col;
+          ColTexel4 tx4 = {0, 0, 0, 0, 0.f, 0.f};
+          if (TF == 1 && Q.fast_tf) {
+            int s0, s1, t0, t1;
+            float fs, ft;
+            smk_lin_clamp(__fmaf_rn(ch0, (float)P.sv, -0.5f), P.sv, s0, s1, fs);
+            smk_lin_clamp(__fmaf_rn(ch1, (float)P.sg, -0.5f), P.sg, t0, t1, ft);
+            bool maybe = true;
+            if (Q.use_occ) maybe = (occ[__mul24(t0, P.occ_roww) + (s0 >> 5)] >> (s0 & 31)) & 1u;
+            col.w = 0.0f;
+            if (maybe) {
+              tx4 = col_tex2d_fetch(P.tf_vg, P.sv, s0, t0, fs, ft);
+              col.w = col_tex_chan(tx4, 3);
+              if (Q.use_ah) {
                 ch2 = tri_h();
-                hit = smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col);
+                int h0, h1;
+                float fh;
+                smk_lin_clamp(__fmaf_rn(ch2, (float)P.sv, -0.5f), P.sv, h0, h1, fh);
+                col.w *= smk_lerp(ah[h0], ah[h0 + 1], fh) * SMK_INV255;
               }
-            } else {
+              col.w = smk_sat(col.w);
+            }
+            hit = col.w != 0.0f;
+          } else if (TF == 2 && Q.use_occ) {
+            int s0, s1, t0, t1;
+            float fs, ft;
+            smk_lin_clamp(__fmaf_rn(ch0, (float)P.s3v, -0.5f), P.s3v, s0, s1, fs);
+            smk_lin_clamp(__fmaf_rn(ch1, (float)P.s3g, -0.5f), P.s3g, t0, t1, ft);
+            col.w = 0.0f;
+            if ((occ[__mul24(t0, P.occ_roww) + (s0 >> 5)] >> (s0 & 31)) & 1u) {
+              ch2 = tri_h();
               hit = smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col);
             }
-            if (hit) {
-              if (TF == 1 && Q.fast_tf) {
-                col.x = col_tex_chan(tx4, 0);
-                col.y = col_tex_chan(tx4, 1);
-                col.z = col_tex_chan(tx4, 2);
-              }
-              float4 src;
-              if (TF == 0) {
-                src = col;
-              } else if (SH == 0) {
-                src = smk_shade_sample<0>(P, col, 0.f, 0.f, 0.f, 0.f);
-              } else {
-                uint32_t nb[8];
+          } else {
+            hit = smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col);
+          }
+          if (hit) {
+            if (TF == 1 && Q.fast_tf) {
+              col.x = col_tex_chan(tx4, 0);
+              col.y = col_tex_chan(tx4, 1);
+              col.z = col_tex_chan(tx4, 2);
+            }
+            float4 src;
+            if (TF == 0) {
+              src = col;
+            } else if (SH == 0) {
+              src = smk_shade_sample<0>(P, col, 0.f, 0.f, 0.f, 0.f);
+            } else {
+              uint32_t nb[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                  if constexpr (DT == 1) nb[k] = __float_as_uint(rq[r][k].w);
-                  else nb[k] = rq[r][k].y;
-                }
-#define NB(dx, dy, dz) nb[QI(dx, dy, dz)]
-                float n0 = smk_nrm(NB(0, 0, 0), NB(1, 0, 0), NB(0, 1, 0), NB(1, 1, 0), NB(0, 0, 1), NB(1, 0, 1), NB(0, 1, 1), NB(1, 1, 1), 0, fxr, fyr, fzr);
-                float n1 = smk_nrm(NB(0, 0, 0), NB(1, 0, 0), NB(0, 1, 0), NB(1, 1, 0), NB(0, 0, 1), NB(1, 0, 1), NB(0, 1, 1), NB(1, 1, 1), 1, fxr, fyr, fzr);
-                float n2 = smk_nrm(NB(0, 0, 0), NB(1, 0, 0), NB(0, 1, 0), NB(1, 1, 0), NB(0, 0, 1), NB(1, 0, 1), NB(0, 1, 1), NB(1, 1, 1), 2, fxr, fyr, fzr);
-#undef NB
-                src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1);
+              for (int k = 0; k < 8; ++k) {
+                if constexpr (DT == 1) nb[k] = __float_as_uint(rq[k].w);
+                else nb[k] = rq[k].y;
               }
-              if (P.blend == SMK_BLEND_MAX) {
-                y.C0 = fmaxf(y.C0, src.x);
-                y.C1 = fmaxf(y.C1, src.y);
-                y.C2 = fmaxf(y.C2, src.z);
-                y.C3 = fmaxf(y.C3, src.w);
-              } else {
-                const float w = 1.0f - y.C3;
-                y.C0 = __fmaf_rn(w, src.x, y.C0);
-                y.C1 = __fmaf_rn(w, src.y, y.C1);
-                y.C2 = __fmaf_rn(w, src.z, y.C2);
-                y.C3 = __fmaf_rn(w, src.w, y.C3);
+#define NB(dx, dy, dz) nb[QI(dx, dy, dz)]
+              float n0 = smk_nrm(NB(0, 0, 0), NB(1, 0, 0), NB(0, 1, 0), NB(1, 1, 0), NB(0, 0, 1), NB(1, 0, 1), NB(0, 1, 1), NB(1, 1, 1), 0, fx, fy, fz);
+              float n1 = smk_nrm(NB(0, 0, 0), NB(1, 0, 0), NB(0, 1, 0), NB(1, 1, 0), NB(0, 0, 1), NB(1, 0, 1), NB(0, 1, 1), NB(1, 1, 1), 1, fx, fy, fz);
+              float n2 = smk_nrm(NB(0, 0, 0), NB(1, 0, 0), NB(0, 1, 0), NB(1, 1, 0), NB(0, 0, 1), NB(1, 0, 1), NB(0, 1, 1), NB(1, 1, 1), 2, fx, fy, fz);
+#undef NB
+              src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1);
+            }
+            if (P.blend == SMK_BLEND_MAX) {
+              y.C0 = fmaxf(y.C0, src.x);
+              y.C1 = fmaxf(y.C1, src.y);
+              y.C2 = fmaxf(y.C2, src.z);
+              y.C3 = fmaxf(y.C3, src.w);
+            } else {
+              const float w = 1.0f - y.C3;
+              y.C0 = __fmaf_rn(w, src.x, y.C0);
+              y.C1 = __fmaf_rn(w, src.y, y.C1);
+              y.C2 = __fmaf_rn(w, src.z, y.C2);
+              y.C3 = __fmaf_rn(w, src.w, y.C3);
+              // exact early termination inside the segment: once A == 1.0f no later sample of this job can change it
+              if (y.C3 == 1.0f && !last) {
+                last = true;
+                npb = COL_DONE;
               }
             }
+          }
 #undef TRI
 #undef QI
-          }
-          if (Q.counts) n_visible += (unsigned)__popcll(__ballot(hit));
-          if (act[r] && !sw[r]) {
-            // exact early termination inside the segment: once A == 1.0f no later sample of this job can change it;
-            // the lane then idles until the box drops the pixel (found by the search in take_next)
-            y.m += 1;
-            y.pb = npb[r];
-            y.sc = nsc[r];
-            y.bi = nbi[r];
-          }
         }
-        // ---- rays whose pixel the box has dropped (or that ran out of planes / of the job): write the segment, take the
-        // pixel that entered.  Eight lanes of a wave at a time when a lattice row or column is replaced.
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          if (__any(sw[r])) {
-            if (sw[r]) {
-              const int from = ray[r].pb + 1;
-              flush(ray[r]);
-              take_next(ray[r], lbr[r], from);
-            }
-          }
+        if (Q.counts) {
+          n_iters += 1;
+          n_act += (unsigned)__popcll(__ballot(y.pb < COL_DONE));
+          n_samples += (unsigned)__popcll(__ballot(act));
+          n_visible += (unsigned)__popcll(__ballot(hit));
+        }
+        if (act) {
+          y.m += 1;
+          y.pb = npb;
+          y.sc = nsc;
+          y.bi = nbi;
+          if (last) flush();  // the ray leaves the job (or is saturated): its segment; the lane is free
         }
       }
-#pragma unroll
-      for (int r = 0; r < R; ++r) flush(ray[r]);
       if (lane == 0) col_lds_st(&ctl[8 + wave], COL_DONE);
       if (Q.counts) {
         if (lane == 0) {
           if (n_samples) atomicAdd(&Q.counts[0], (unsigned long long)n_samples);
           if (n_visible) atomicAdd(&Q.counts[1], (unsigned long long)n_visible);
+          atomicAdd(&Q.counts[4], (unsigned long long)n_iters);
+          atomicAdd(&Q.counts[5], (unsigned long long)n_act);
+          atomicAdd(&Q.counts[6], (unsigned long long)n_swit);
+          atomicAdd(&Q.counts[7], (unsigned long long)n_swl);
         }
         unsigned seg = n_segments;
         for (int o = 32; o > 0; o >>= 1) seg += __shfl_xor(seg, o);
@@ -772,7 +832,11 @@ __global__ __launch_bounds__((NW + NL) * 64) void smk_k_cols(const RenderParams 
   }
   __syncthreads();
   if (tid == 0 && ctl[0]) *(volatile int *)Q.status = ctl[0];
-  if (tid == 0 && Q.job_ticks) Q.job_ticks[job] = max((unsigned)__builtin_amdgcn_s_memrealtime() - t_begin, 1u);
+  if (tid == 0 && Q.job_ticks) {
+    Q.job_ticks[job] = max((unsigned)__builtin_amdgcn_s_memrealtime() - t_begin, 1u);
+    Q.job_ticks[gridDim.x + job] = t_setup - t_begin;   // (developer statistics: the set-up's share, rays listed)
+    Q.job_ticks[2 * gridDim.x + job] = (unsigned)nrays;
+  }
 }
 
 // ---- resolve: a pixel's segments in key order (front to back), mask cleared for the next frame
@@ -832,9 +896,9 @@ __global__ __launch_bounds__(256) void smk_k_cols_build(const V *src, char *dst,
 
 // ------------------------------------------------------------------------------- host side
 
-template <int DT, int SH, int PERM, int TF, int NW, int NL, int WA, int R>
+template <int DT, int SH, int PERM, int TF, int NW, int NL>
 static hipError_t launch_cols(const RenderParams &P, const ColParams &Q, size_t lds, int njobs, hipStream_t s) {
-  auto k = smk_k_cols<DT, SH, PERM, TF, NW, NL, WA, R>;
+  auto k = smk_k_cols<DT, SH, PERM, TF, NW, NL>;
   static bool attr_set[64] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -847,16 +911,15 @@ static hipError_t launch_cols(const RenderParams &P, const ColParams &Q, size_t 
   return hipGetLastError();
 }
 
-// workgroup shapes: {NW, NL, WA, R}
-struct ColShape { int nw, nl, wa, r; };
-static const ColShape kColShapes[] = {{15, 1, 5, 1}, {14, 2, 7, 2}, {12, 2, 4, 2}};
+// workgroup shapes: {consumer waves, loader waves}
+struct ColShape { int nw, nl; };
+static const ColShape kColShapes[] = {{15, 1}, {14, 2}};
 
 template <int DT, int SH, int PERM, int TF>
 static hipError_t dispatch_shape(const RenderParams &P, const ColParams &Q, int shape, size_t lds, int njobs, hipStream_t s) {
   switch (shape) {
-    case 0: return launch_cols<DT, SH, PERM, TF, 15, 1, 5, 1>(P, Q, lds, njobs, s);
-    case 1: return launch_cols<DT, SH, PERM, TF, 14, 2, 7, 2>(P, Q, lds, njobs, s);
-    case 2: return launch_cols<DT, SH, PERM, TF, 12, 2, 4, 2>(P, Q, lds, njobs, s);
+    case 0: return launch_cols<DT, SH, PERM, TF, 15, 1>(P, Q, lds, njobs, s);
+    case 1: return launch_cols<DT, SH, PERM, TF, 14, 2>(P, Q, lds, njobs, s);
   }
   return hipErrorInvalidValue;
 }
@@ -985,8 +1048,8 @@ hipError_t smk_launch_cols(RenderParams P, int dtype, int tf_mode, int shade_kin
       Q.Mw[a] = (float)(Q.Mw[a] / wc);
     }
   }
-  // ---- workgroup shape and column size.  The pixel footprint of a column of CW x CH cells (widest where the volume
-  // is nearest to the eye) must fit the lattice with room for the box's drift over one position and rounding.
+  // ---- workgroup shape and column size.  Every ray that is inside a column at one slice position wants a lane: cells x
+  // rays per cell (largest where the volume is nearest to the eye) must stay below the consumer lanes.
   const int vb = dtype == 0 ? 8 : 16;
   auto project = [&](double u, double v, double sc, double &x, double &y) -> bool {
     double X[3];
@@ -997,40 +1060,39 @@ hipError_t smk_launch_cols(RenderParams P, int dtype, int tf_mode, int shade_kin
     y = (Q.My[0] * X[0] + Q.My[1] * X[1] + Q.My[2] * X[2] + Q.My[3]) / w;
     return true;
   };
-  // Jacobian d(pixel)/d(u, v, s) at the volume corners and centre: the largest magnitudes bound a column's footprint
-  double Jxu = 0, Jxv = 0, Jyu = 0, Jyv = 0, Jxs = 0, Jys = 0;
+  // pixels per (u, v) cell of a slice at the volume's corners and centre
+  double dens = 0, flux = 0;
   for (int c = 0; c < 9; ++c) {
     const double u = c == 8 ? 0.5 * P.N[au] : ((c & 1) ? P.N[au] - 0.5 : -0.5), v = c == 8 ? 0.5 * P.N[av] : ((c & 2) ? P.N[av] - 0.5 : -0.5),
                  sc = c == 8 ? 0.5 * P.N[as] : ((c & 4) ? P.N[as] - 0.5 : -0.5);
-    double x0, y0, x1, y1;
-    if (!project(u, v, sc, x0, y0)) { *why = "volume reaches behind the eye"; return hipErrorNotSupported; }
-    if (!project(u + 1, v, sc, x1, y1)) { *why = "volume reaches behind the eye"; return hipErrorNotSupported; }
-    Jxu = std::max(Jxu, fabs(x1 - x0)); Jyu = std::max(Jyu, fabs(y1 - y0));
-    if (!project(u, v + 1, sc, x1, y1)) { *why = "volume reaches behind the eye"; return hipErrorNotSupported; }
-    Jxv = std::max(Jxv, fabs(x1 - x0)); Jyv = std::max(Jyv, fabs(y1 - y0));
-    if (!project(u, v, sc + 1, x1, y1)) { *why = "volume reaches behind the eye"; return hipErrorNotSupported; }
-    Jxs = std::max(Jxs, fabs(x1 - x0)); Jys = std::max(Jys, fabs(y1 - y0));
+    double x0, y0, x1, y1, x2, y2, x3, y3;
+    if (!project(u, v, sc, x0, y0) || !project(u + 1, v, sc, x1, y1) || !project(u, v + 1, sc, x2, y2) || !project(u, v, sc + 1, x3, y3)) {
+      *why = "volume reaches behind the eye";
+      return hipErrorNotSupported;
+    }
+    dens = std::max(dens, fabs((x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0)));
+    flux = std::max(flux, std::max(fabs(x3 - x0), fabs(y3 - y0)));
   }
+  (void)flux;
+  if (!(dens > 1e-9)) { *why = "degenerate projection"; return hipErrorNotSupported; }
   int shape = opt_shape ? opt_shape - 1 : 0;
   if (shape < 0 || shape >= (int)(sizeof kColShapes / sizeof kColShapes[0])) { *why = "no such workgroup shape"; return hipErrorNotSupported; }
   const ColShape &S = kColShapes[shape];
-  const int La = 8 * S.wa, Lb = S.r * 8 * (S.nw / S.wa);
-  // LDS: ring + table + control + alpha_H + occupancy bitmap
+  const int lanes = S.nw * 64;
+  // LDS: ring + ray list + entry positions + slot table + two histograms + control + alpha_H + occupancy bitmap
   const bool three = P.third_axis && P.tf_h;
   const int use_ah = (tf_mode == 1 && three && P.nelts <= 3 && P.sv >= 2 && P.sv <= 1024) ? 1 : 0;
   const int fast_tf = (tf_mode == 1 && (!three || use_ah)) ? 1 : 0;
   const size_t occ_bytes = tf_mode == 1 ? (size_t)P.occ_roww * P.sg * 4 : tf_mode == 2 ? (size_t)P.occ_roww * P.s3g * 4 : 0;
   const int use_occ = (P.tf_occ && occ_bytes > 0 && occ_bytes <= 16384 && (fast_tf || tf_mode == 2)) ? 1 : 0;
-  const size_t fixed = (size_t)(COL_MAX_CL + 2) * sizeof(ColEnt) + 32 * 4 + (use_ah ? (size_t)P.sv * 4 : 0) + (use_occ ? occ_bytes : 0) + 64;
+  const size_t fixed = (size_t)COL_MAX_RAYS * 9 + (size_t)3 * (COL_MAX_CL + 4) * 4 + 32 * 4 + (use_ah ? (size_t)P.sv * 4 : 0) + (use_occ ? occ_bytes : 0) + 64;
   const size_t lds_cap = 160 * 1024;
-  const int want_slots = opt_ns ? opt_ns : 5;
-  // choose (CW, CH): footprint fits the lattice, the ring fits LDS, least halo overhead
-  const double margin = 2.0 + 2.0 * COL_BOX_MARGIN;
+  const int want_slots = opt_ns ? opt_ns : 6;
   ColLayout &LY = aux->lay[perm];
   const int cells_u = Q.Du - 1, cells_v = Q.Dv - 1;
+  const double fill = (aux->opt_fill > 0 ? aux->opt_fill : 92) * 0.01;  // of the lanes, at the densest place (the set-up checks every job exactly and reports, see the kernel)
   auto fits = [&](int cw, int ch, int slots) -> bool {
-    const double fx = Jxu * cw + Jxv * ch + Jxs + margin, fy = Jyu * cw + Jyv * ch + Jys + margin;
-    if (fx > La || fy > Lb) return false;
+    if ((double)cw * ch * dens > fill * lanes) return false;
     const size_t sb = (((size_t)(cw + 1) * (ch + 1) * vb) + 15) & ~(size_t)15;
     if (sb * slots + fixed > lds_cap) return false;
     if ((sb + 1023) / 1024 * 2 > 63) return false;  // two slices in flight per loader within the vmcnt range
@@ -1038,25 +1100,28 @@ hipError_t smk_launch_cols(RenderParams P, int dtype, int tf_mode, int shade_kin
   };
   bool reuse = LY.d && LY.Du == Q.Du && LY.Dv == Q.Dv && LY.Ds == Q.Ds && LY.src == vox_native && LY.vb == vb;
   if (reuse) {
-    // an existing layout is kept while its columns fit the lattice and are not wastefully small for the view
-    const double fx = Jxu * LY.CW + Jxv * LY.CH, fy = Jyu * LY.CW + Jyv * LY.CH;
-    reuse = fits(LY.CW, LY.CH, 3) && (fx > 0.55 * La || LY.CW >= cells_u) && (fy > 0.55 * Lb || LY.CH >= cells_v);
+    // an existing layout is kept while its columns fit the lanes and are not wastefully small for the view
+    reuse = fits(LY.CW, LY.CH, 3) && ((double)LY.CW * LY.CH * dens > 0.45 * lanes || (LY.CW >= cells_u && LY.CH >= cells_v));
   }
   if (!reuse) {
+    // columns as balanced divisions of the box: the squarest pair that fits, most cells first (least halo)
     int bw = 0, bh = 0;
     double best = 1e300;
-    for (int cw = 2; cw <= std::min(cells_u, 255); ++cw)
-      for (int ch = 2; ch <= std::min(cells_v, 255); ++ch) {
+    for (int ncu = 1; ncu <= cells_u; ++ncu) {
+      const int cw = (cells_u + ncu - 1) / ncu;
+      if (cw > 255) continue;
+      if (ncu > 1 && (cells_u + ncu - 2) / (ncu - 1) == cw) continue;  // (same width as with one column fewer)
+      for (int ncv = 1; ncv <= cells_v; ++ncv) {
+        const int ch = (cells_v + ncv - 1) / ncv;
+        if (ch > 255) continue;
+        if (ncv > 1 && (cells_v + ncv - 2) / (ncv - 1) == ch) continue;
         if (!fits(cw, ch, want_slots)) continue;
-        // bytes streamed per cell, columns rounded up to cover the box
-        const int ncu = (cells_u + cw - 1) / cw, ncv = (cells_v + ch - 1) / ch;
         const double over = (double)ncu * (cw + 1) * (double)ncv * (ch + 1) / ((double)cells_u * cells_v);
         if (over < best) { best = over; bw = cw; bh = ch; }
       }
-    if (!bw) { *why = "no column size fits the lattice (view too close)"; return hipErrorNotSupported; }
+    }
+    if (!bw) { *why = "no column size fits the lanes (view too close)"; return hipErrorNotSupported; }
     const int ncu = (cells_u + bw - 1) / bw, ncv = (cells_v + bh - 1) / bh;
-    bw = (cells_u + ncu - 1) / ncu;  // balanced: the last column is not a sliver
-    bh = (cells_v + ncv - 1) / ncv;
     const size_t sb = (((size_t)(bw + 1) * (bh + 1) * vb) + 15) & ~(size_t)15;
     const size_t bytes = (size_t)ncu * ncv * Q.Ds * sb;
     size_t free_b = 0, total_b = 0;
@@ -1097,10 +1162,12 @@ hipError_t smk_launch_cols(RenderParams P, int dtype, int tf_mode, int shade_kin
   nslots = std::min(nslots, 12);
   if (nslots < 3) { *why = "column slice does not fit LDS three times"; return hipErrorNotSupported; }
   Q.nslots = nslots;
-  Q.maxfly = std::max(1, std::min(2, (nslots - 2) / S.nl));
-  if (Q.n_ch * Q.maxfly > 63) Q.maxfly = 1;
+  Q.maxfly = std::max(1, std::min(aux->opt_fly > 0 ? aux->opt_fly : 2, (nslots - 2) / S.nl));
+  while (Q.maxfly > 1 && Q.n_ch * Q.maxfly > 63) --Q.maxfly;  // (the counted vmcnt wait takes an immediate < 64)
   if (Q.n_ch > 63) { *why = "column slice needs more than 63 DMA instructions"; return hipErrorNotSupported; }
-  Q.wstep = opt_wstep ? opt_wstep - 1 : (nslots >= 6 ? 1 : 0);
+  Q.wstep = opt_wstep ? opt_wstep - 1 : (nslots >= 7 ? 2 : nslots >= 5 ? 1 : 0);
+  Q.take_min = aux->opt_take_min > 0 ? aux->opt_take_min : 16;
+  Q.take_wait = aux->opt_take_wait > 0 ? aux->opt_take_wait - 1 : 3;
   const int npos_total = Q.Ds - 1;
   int clmax = opt_cl ? std::min(opt_cl, COL_MAX_CL) : 128;
   clmax = std::max(clmax, 4);
@@ -1136,11 +1203,11 @@ hipError_t smk_launch_cols(RenderParams P, int dtype, int tf_mode, int shade_kin
   if (njobs > aux->ticks_cap) {
     if (aux->d_ticks) (void)hipFree(aux->d_ticks);
     aux->d_ticks = nullptr; aux->ticks_cap = 0;
-    if (hipMalloc((void **)&aux->d_ticks, (size_t)njobs * 4) != hipSuccess) { (void)hipGetLastError(); *why = "no memory"; return hipErrorNotSupported; }
+    if (hipMalloc((void **)&aux->d_ticks, (size_t)njobs * 12) != hipSuccess) { (void)hipGetLastError(); *why = "no memory"; return hipErrorNotSupported; }
     aux->ticks_cap = njobs;
   }
   if (!aux->d_counts) {
-    if (hipMalloc((void **)&aux->d_counts, 4 * 8) != hipSuccess) { (void)hipGetLastError(); *why = "no memory"; return hipErrorNotSupported; }
+    if (hipMalloc((void **)&aux->d_counts, 8 * 8) != hipSuccess) { (void)hipGetLastError(); *why = "no memory"; return hipErrorNotSupported; }
   }
   Q.layers = (float4 *)aux->d_layers;
   Q.masks = (unsigned long long *)aux->d_masks;
@@ -1148,13 +1215,13 @@ hipError_t smk_launch_cols(RenderParams P, int dtype, int tf_mode, int shade_kin
   Q.job_ticks = aux->d_ticks;
   Q.counts = aux->want_counts ? aux->d_counts : nullptr;
   if (Q.counts) {
-    hipError_t e = hipMemsetAsync(aux->d_counts, 0, 32, s);
+    hipError_t e = hipMemsetAsync(aux->d_counts, 0, 64, s);
     if (e != hipSuccess) return e;
   }
   aux->njobs_last = njobs;
   aux->last = Q.CW | (Q.CH << 8) | (nslots << 16) | (shape << 24);
   aux->last_stream_bytes = (double)njobs / Q.nck * ((double)npos_total + Q.nck) * Q.slice_bytes;
-  Q.ring_bytes = (int)std::max((size_t)nslots * Q.slice_bytes, (size_t)6 * COL_MAX_CL * 4);
+  Q.ring_bytes = (int)std::max((size_t)nslots * Q.slice_bytes, (size_t)COL_MAX_RAYS * 16);  // (set-up scratch: the unsorted rays)
   const size_t lds = (size_t)Q.ring_bytes + fixed;
   if (lds > lds_cap) { *why = "column job does not fit LDS"; return hipErrorNotSupported; }
   if (aux->frame_ev0) {

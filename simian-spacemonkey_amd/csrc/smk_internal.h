@@ -122,8 +122,9 @@ struct ColsAux {
   int mask_words_last = 0;
   unsigned *d_ticks = nullptr;  // [njobs] workgroup durations of the latest frame (100 MHz ticks)
   int ticks_cap = 0, njobs_last = 0;
-  unsigned long long *d_counts = nullptr;  // [4] samples taken | visible | slices streamed | segments written
+  unsigned long long *d_counts = nullptr;  // [8] developer statistics of the latest frame (ColParams::counts)
   int want_counts = 0;
+  int opt_fill = 0, opt_take_min = 0, opt_take_wait = 0, opt_fly = 0;  // developer knobs (smk_set_option cols_fill / cols_take_min / cols_take_wait)
   int builds = 0;               // layouts built so far
   int last = 0;                 // CW | CH << 8 | nslots << 16 | shape << 24 of the latest launch
   double last_stream_bytes = 0; // bytes the loaders of the latest launch had to stream

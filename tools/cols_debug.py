@@ -15,7 +15,7 @@ import oracle  # noqa: E402
 
 pkg = load_package()
 R = pkg.Renderer(0)
-cases = [("cfg3", "rot", True, 1, 64, 64), ("cfg4", "z-", False, 1, 72, 80), ("cfg4", "x+", True, 1, 72, 80), ("cfg2", "y-", True, 0, 96, 100),
+cases = [("cfg3", "rot", True, 1, 64, 9), ("cfg3", "x-", False, 1, 90, 13), ("cfg3", "rot", True, 1, 64, 64), ("cfg4", "z-", False, 1, 72, 80), ("cfg4", "x+", True, 1, 72, 80), ("cfg2", "y-", True, 0, 96, 100),
          ("tf3d_panes", "diag", True, 1, 64, 64), ("cfg1", "diag", False, 0, 64, 64)]
 for kind, pose, f32, shade, size, steps in cases:
     sc = make_scene(kind, n=32, size=size, steps=steps, pose=pose, f32=f32, shade=shade)

@@ -79,6 +79,10 @@ def main():
                 t, kms, kn = bench.timed(r, a.frames, 2, frame, 1, None)
         except Exception as ex:  # (a forced configuration the launcher refuses: say so, go on with the next variant)
             print("%-32s refused: %s" % (var, str(ex).strip().splitlines()[-1][:150]), flush=True)
+            try:
+                r.render_device(frame.data_ptr())   # (a flagged frame makes the next call fail once: take that here)
+            except Exception:
+                pass
             continue
         kern, _, alg = r.last_frame_info()
         img = frame.cpu().numpy()
@@ -94,12 +98,14 @@ def main():
         if kern == 4:
             cfg = int(r.stat("cols_config"))
             sb = r.stat("cols_stream_bytes")
-            print("   column-stream: CW x CH %d x %d, %d slots, shape %d, %d jobs; streamed %.2f GB = %.2f x alg -> %.0f GB/s; jobs: longest %.3f ms, sum %.1f ms (= %.3f ms per CU of 256); layouts built %d" %
+            print("   column-stream: CW x CH %d x %d, %d slots, shape %d, %d jobs; streamed %.2f GB = %.2f x alg -> %.0f GB/s; jobs: longest %.3f ms, sum %.1f ms (= %.3f ms per CU of 256), of which set-up %.1f ms; rays listed %.4g; layouts built %d" %
                   (cfg & 255, (cfg >> 8) & 255, (cfg >> 16) & 255, cfg >> 24, r.stat("cols_jobs"), sb / 1e9, sb / alg, sb / (kms * 1e-3) / 1e9,
-                   r.stat("cols_job_ms_max"), r.stat("cols_job_ms_sum"), r.stat("cols_job_ms_sum") / 256, r.stat("cols_builds")), flush=True)
+                   r.stat("cols_job_ms_max"), r.stat("cols_job_ms_sum"), r.stat("cols_job_ms_sum") / 256, r.stat("cols_setup_ms_sum"), r.stat("cols_rays"), r.stat("cols_builds")), flush=True)
             if any(kv.split("=")[0] == "cols_counts" and int(kv.split("=")[1]) for kv in var.split(",")):
-                print("   samples taken %.4g, visible %.4g, slices streamed %.4g, segments %.4g" %
-                      (r.stat("cols_samples"), r.stat("cols_visible"), r.stat("cols_slices"), r.stat("cols_segments")), flush=True)
+                it = r.stat("cols_iters") + 1e-9
+                print("   samples taken %.4g, visible %.4g, slices streamed %.4g, segments %.4g; consumer wave-iterations %.4g: lanes with a sample %.1f%% of 64, taking one %.1f%%; iterations with a ray change %.1f%%, %.1f lanes each" %
+                      (r.stat("cols_samples"), r.stat("cols_visible"), r.stat("cols_slices"), r.stat("cols_segments"), it, 100 * r.stat("cols_active_lanes") / (64 * it),
+                       100 * r.stat("cols_samples") / (64 * it), 100 * r.stat("cols_switch_iters") / it, r.stat("cols_switch_lanes") / (r.stat("cols_switch_iters") + 1e-9)), flush=True)
         if kern == 2:
             print("   workgroups: longest %.3f ms, sum %.1f ms (= %.3f ms on every workgroup slot of 256 CUs x 2)" %
                   (r.stat("slab_tile_ms_max"), r.stat("slab_tile_ms_sum"), r.stat("slab_tile_ms_sum") / 512), flush=True)
