@@ -106,6 +106,9 @@ extern "C" void smk_destroy(smk_ctx *c) {
   if (c->slab.h_status) (void)hipHostFree(c->slab.h_status);
   if (c->slab.d_diag) (void)hipFree(c->slab.d_diag);
   if (c->slab.d_order) (void)hipFree(c->slab.d_order);
+  if (c->slab.d_pticks) (void)hipFree(c->slab.d_pticks);
+  if (c->slab.h_pticks) (void)hipHostFree(c->slab.h_pticks);
+  if (c->slab.d_seg) (void)hipFree(c->slab.d_seg);
   for (int k = 0; k < 4; ++k) {
     if (c->slab.h_order[k]) (void)hipHostFree(c->slab.h_order[k]);
     if (c->slab.order_ev[k]) (void)hipEventDestroy(c->slab.order_ev[k]);
@@ -1021,6 +1024,7 @@ extern "C" int smk_set_option(smk_ctx *c, const char *key, int value) {
   else if (!strcmp(key, "slab_sched")) c->opt_slab_sched = value < 0 ? 0 : (value > 15 ? 15 : value);
   else if (!strcmp(key, "slab_ns")) c->opt_slab_ns = value < 0 ? 0 : (value > 63 ? 63 : value);
   else if (!strcmp(key, "tile")) c->opt_tile = value;
+  else if (!strcmp(key, "slab_split")) c->slab.opt_split = value < 0 ? 0 : (value > 8 ? 8 : value);
   else if (!strcmp(key, "cols_shape")) c->opt_cols = (c->opt_cols & ~0xff) | (value & 0xff);
   else if (!strcmp(key, "cols_ns")) c->opt_cols = (c->opt_cols & ~0xff00) | ((value & 0xff) << 8);
   else if (!strcmp(key, "cols_chunk")) c->opt_cols = (c->opt_cols & ~0xfff0000) | ((value & 0xfff) << 16);
@@ -1186,7 +1190,9 @@ extern "C" int smk_get_stat(smk_ctx *c, const char *name, double *value) {
       HIPCHK(c, hipMemcpy(h.data(), c->slab.d_ticks, (size_t)nt * 4, hipMemcpyDeviceToHost));
       double mx = 0, sum = 0;
       for (int t = 0; t < nt; ++t) {
-        mx = std::max(mx, (double)h[t]);
+        // (a split tile's word is the sum over its pieces: the longest workgroup is taken as an equal share)
+        const double k = t < (int)c->slab.ksplit_last.size() ? std::max<int>(c->slab.ksplit_last[t], 1) : 1;
+        mx = std::max(mx, (double)h[t] / k);
         sum += h[t];
       }
       *value = (name[13] == 'm' ? mx : sum) * 1e-5;  // 100 MHz ticks
@@ -1240,6 +1246,8 @@ extern "C" int smk_get_stat(smk_ctx *c, const char *name, double *value) {
       }
     FAIL(c, "smk_get_stat: unknown name '%s'", name);
   }
+  if (!strcmp(name, "slab_split_tiles")) { *value = c->slab.nsplit_last; return 0; }
+  if (!strcmp(name, "slab_workgroups")) { *value = c->slab.nblocks_last; return 0; }
   if (!strcmp(name, "slab_retries")) {
     *value = (double)c->slab_retries;
     return 0;

@@ -77,12 +77,12 @@ struct SlabAux {
   int status_slot = 0;          // the word of the frame being launched
   hipEvent_t frame_ev0 = nullptr;  // recorded by the launcher right before its first stream operation
   float *d_diag = nullptr;      // [16] diagnostic counters (option lockstep bit 16)
-  int *d_order = nullptr;       // tile schedule of the current camera
-  int *h_order[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned staging copies, used in turn
+  int2 *d_order = nullptr;      // workgroup schedule of the current camera
+  int2 *h_order[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned staging copies, used in turn
   hipEvent_t order_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // completion of each one's last copy
   int order_next = 0;
   int order_cap = 0;
-  std::vector<int> order_host;  // what d_order holds
+  std::vector<int2> order_host;  // what d_order holds
   struct Scan {  // the per-tile geometry scan of the last frame, per workgroup configuration tried (key = camera + region + tile shape)
     std::vector<unsigned char> key;
     double v[4] = {0, 0, 0, 0};
@@ -91,7 +91,9 @@ struct SlabAux {
   unsigned scan_next = 0;
   std::vector<unsigned char> shape_key;  // the small-workgroup shape chosen for this view class (see the launcher's probing pass)
   int shape_choice = -1, shape_age = 0;
-  std::vector<int> plan_work, plan_order;  // the weights the last schedule was built from, and that schedule
+  std::vector<int> plan_work;   // the weights the last schedule was built from,
+  std::vector<unsigned char> plan_cuts;  // the cuts,
+  std::vector<int2> plan_order;  // and that schedule
   int plan_slots = 0;
   // per-tile workgroup durations of an earlier frame: the schedule's weights
   unsigned *d_ticks = nullptr, *h_ticks = nullptr;  // device buffer the kernel writes; pinned copy in flight
@@ -101,6 +103,18 @@ struct SlabAux {
   long long ticks_pending_sig = 0, ticks_good_sig = -1;
   hipEvent_t ticks_ev = nullptr;
   std::vector<unsigned> ticks_good;
+  // DEPTH SEGMENTS (smk_slab.hip): partial frames of the pieces 1.. of split tiles, [maxseg - 1][W * H] float4
+  void *d_seg = nullptr;
+  size_t seg_cap = 0;
+  int opt_split = 0;            // option "slab_split": 0 auto, 1 off, 2.. forced
+  int nsplit_last = 0, nblocks_last = 0;
+  std::vector<unsigned char> ksplit_last;  // pieces per tile of the latest launch
+  unsigned *d_pticks = nullptr, *h_pticks = nullptr;  // [ntiles][8] durations of the pieces of split tiles (device; pinned copy)
+  std::vector<unsigned> pticks_good;                   // the latest that came back ...
+  std::vector<unsigned char> cuts, cuts_pending, cuts_good;  // [ntiles][10] {K, cut_0..cut_K}: current | of the copy in flight | of pticks_good
+  int cuts_split = -1;
+  long long cuts_sig = -1;
+  bool recut = true, cuts_engaged = false;
   unsigned *d_trace = nullptr;  // [trace_n][8] workgroup timeline of the last traced frame (option lockstep bit 32)
   int trace_cap = 0, trace_n = 0;
 };

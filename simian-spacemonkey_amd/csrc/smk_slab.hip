@@ -66,7 +66,8 @@ struct SlabParams {
   int fast_tf;                 // alpha-first classification with 8-byte texel loads (no third axis, or use_ah)
   const unsigned char *bricks;  // brick flags of the stored box (smk_bricks.hip) or null: see "EMPTY LAYERS" in the kernel
   int bsu, bsv, bss;           // their strides along U, V, S (in bricks)
-  const int *order;            // tile of each block (work-balanced schedule, -1 = none), see smk_launch_slab
+  const int2 *order;           // workgroup of each block: {tile | piece << 20 | pieces << 26, cut fractions lo | hi << 8} (work-balanced
+                               // schedule, .x = -1: none), see smk_launch_slab and DEPTH SEGMENTS
   unsigned *tile_ticks;        // [3][ntiles]: duration of each tile's workgroup in 100 MHz ticks (next frame's weights) |
                                // slices its loaders streamed | slices of its range (the loaders stop once every ray of
                                // the tile is saturated: what was NOT streamed is not counted as read, smk_last_frame_info)
@@ -74,6 +75,8 @@ struct SlabParams {
   int *status;                 // host-visible word: 1 = protocol time-out, 2 = window bound violated
   float *diag;                 // [16] diagnostic counters (lockstep bit 16) or null
   unsigned *trace;             // [nblocks][8] per-workgroup timeline record (lockstep bit 32, see smk.h) or null
+  float4 *seg_out;             // [maxseg - 1][W * H]: partial frames of the depth segments 1.. of split tiles (DEPTH SEGMENTS), or null
+  unsigned *piece_ticks;       // [ntiles][8]: duration of every piece of a split tile (where the next cuts come from)
 };
 
 #define SLAB_EPS 0.02f
@@ -291,8 +294,12 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   // occupancy bitmap of the (V,G) table (smk_api.hip refresh_tf2d), a copy per workgroup
   const uint32_t *occ = reinterpret_cast<const uint32_t *>(ah + (Q.use_ah ? P.sv : 0));
 
-  const int tile = Q.order[blockIdx.x];
-  if (tile < 0) return;  // whole workgroup leaves together
+  // order entry: tile | segment << 20 | segments of the tile << 26 (DEPTH SEGMENTS below); -1 = none
+  const int2 oent = Q.order[blockIdx.x];
+  const int ocode = oent.x;
+  if (ocode < 0) return;  // whole workgroup leaves together
+  const int tile = ocode & 0xfffff, seg = (ocode >> 20) & 63, nseg = max((ocode >> 26) & 31, 1);
+  const int cut_lo = oent.y & 255, cut_hi = (oent.y >> 8) & 255;  // this piece's share of the tile's slice positions, in 255ths
   const bool flags = BR && Q.bricks != nullptr;
   const bool tracing = DIAG && Q.trace != nullptr && (P.lockstep & 32);  // (diagnostic: workgroup timeline)
   // the workgroup's duration feeds the next frame's schedule (see smk_launch_slab): one scalar
@@ -421,7 +428,50 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
     }
   }
   __syncthreads();
-  const int smin = ctl[0], smax = ctl[1];
+  int smin = ctl[0], smax = ctl[1];
+  // ---- DEPTH SEGMENTS.  A tile whose workgroup would run long (measured, see the launcher) is rendered by `nseg`
+  // workgroups: the positions of its slice range are cut into nseg runs (where, the launcher decides from the pieces'
+  // measured durations: equal WORK, not equal depth), workgroup `seg` takes the samples whose base
+  // slice lies in its run -- base slices are monotone in the plane index, so a ray's share is a sub-interval of its
+  // planes, found by an estimate and the exact evaluation -- and writes a partial frame; the partial frames are merged
+  // in marching order afterwards (smk_k_slab_merge: front-to-back over, or max).  What changes is the association of
+  // the blend, nothing else: the frame agrees with the unsplit one to a few ulp per segment.
+  if (nseg > 1 && smin <= smax) {
+    const int np_full = smax - smin + 1;
+    const int q0 = (int)((long long)cut_lo * np_full / 255), q1 = (int)((long long)cut_hi * np_full / 255);  // positions [q0, q1)
+    // base slices of this segment
+    const int b_lo = Q.dir > 0 ? smin + q0 : smax - q1 + 1, b_hi = Q.dir > 0 ? smin + q1 - 1 : smax - q0;
+    if (m <= m1) {
+      if (q1 <= q0) {
+        m1 = m - 1;
+      } else {
+        const float inv = 1.0f / B[AS];
+        // first plane whose base slice is inside [b_lo, b_hi] in marching order: s reaches the run's near face
+        const float s_near = Q.dir > 0 ? (float)b_lo : (float)(b_hi + 1), s_far = Q.dir > 0 ? (float)(b_hi + 1) : (float)b_lo;
+        auto in_run = [&](int q) -> bool { const int b = base_slice(q); return b >= b_lo && b <= b_hi; };
+        auto before = [&](int q) -> bool { const int b = base_slice(q); return Q.dir > 0 ? b < b_lo : b > b_hi; };
+        // (at an end of the volume the clamped base slice takes in everything beyond: no estimate, the ray's own end)
+        const bool open_near = Q.dir > 0 ? b_lo <= 0 : b_hi >= NS - 2, open_far = Q.dir > 0 ? b_hi >= NS - 2 : b_lo <= 0;
+        int qa = open_near ? m : max(m, min(m1 + 1, (int)floorf((s_near - A[AS]) * inv) - 1));
+        int qb = open_far ? m1 : min(m1, max(m - 1, (int)ceilf((s_far - A[AS]) * inv) + 1));
+        bool bad = false;
+#pragma unroll 1
+        for (int k = 0; qa <= m1 && before(qa); ++k) { ++qa; if (k > 8) { bad = true; break; } }   // up to the run
+#pragma unroll 1
+        for (int k = 0; qa > m && !before(qa - 1); ++k) { --qa; if (k > 8) { bad = true; break; } }  // (never started inside it)
+#pragma unroll 1
+        for (int k = 0; qb >= qa && !in_run(qb) && !before(qb); ++k) { --qb; if (k > 8) { bad = true; break; } }  // back into the run
+#pragma unroll 1
+        for (int k = 0; qb < m1 && (in_run(qb + 1) || before(qb + 1)); ++k) { ++qb; if (k > 8) { bad = true; break; } }
+        if (bad) ctl[3] = 1;  // the bracket did not close: reported, the frame is rendered again another way
+        m = qa;
+        m1 = (qb >= qa && in_run(qb) && in_run(qa)) ? qb : qa - 1;
+      }
+    }
+    smin = b_lo;
+    smax = b_hi;
+    if (q1 <= q0) { smin = 0x7fffffff; smax = -0x7fffffff; }
+  }
   const bool phases = tracing && (P.lockstep & 128);  // (diagnostic: where the set-up's time goes, instead of the loader's cycles)
   unsigned ph1 = 0, ph2 = 0, ph3 = 0;
   if (phases) ph1 = (unsigned)__builtin_amdgcn_s_memrealtime() - trace_t0;
@@ -1367,14 +1417,21 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   }
   if (live) {
     size_t o = (size_t)j * P.W + i;
-    P.out[o] = make_float4(C0, C1, C2, C3);
+    float4 *outp = seg == 0 ? P.out : Q.seg_out + (size_t)(seg - 1) * ((size_t)P.W * P.H);
+    outp[o] = make_float4(C0, C1, C2, C3);
   }
   // errors are reported, never swallowed: the host turns a non-zero status into a failed frame
   if (npos > 0) {
     __syncthreads();
     if (tid == 0 && ctl[3]) *(volatile int *)Q.status = ctl[3];
   }
-  if (tid == 0 && Q.tile_ticks) {
+  if (tid == 0 && Q.tile_ticks && nseg > 1) {  // (a split tile's words are sums over its workgroups; zeroed by the launcher)
+    const unsigned dur = max((unsigned)__builtin_amdgcn_s_memrealtime() - trace_t0, 1u);
+    if (Q.piece_ticks) Q.piece_ticks[(size_t)tile * 8 + seg] = dur;
+    atomicAdd(&Q.tile_ticks[tile], dur);
+    atomicAdd(&Q.tile_ticks[Q.ntiles + tile], npos > 0 ? (unsigned)max(min(max(min(min(ctl[4], ctl[5]), min(ctl[6], ctl[7])), 0), npos + 1) - ctl[2], 0) : 0u);
+    atomicAdd(&Q.tile_ticks[2 * Q.ntiles + tile], npos > 0 ? (unsigned)(npos + 1) : 0u);
+  } else if (tid == 0 && Q.tile_ticks) {
     Q.tile_ticks[tile] = max((unsigned)__builtin_amdgcn_s_memrealtime() - trace_t0, 1u);
     // (ctl[4..7] = the loaders' landed words, final after the barrier above; their minimum = slices completely streamed)
     // (less the slices that were not streamed because nobody samples them: EMPTY LAYERS)
@@ -1403,6 +1460,33 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 #define SLAB_PART 0
 #endif
 #if SLAB_PART == 0
+// DEPTH SEGMENTS, second half: the partial frames of a split tile, merged in marching order.  `list` entries: tile | segments << 20.
+__global__ __launch_bounds__(256) void smk_k_slab_merge(const int2 *list, int tw, int th, int ntx, int W, int H, const float4 *seg_out, float4 *out, int use_max) {
+  const int code = list[blockIdx.x].x;
+  const int tile = code & 0xfffff, nseg = code >> 20;
+  const int ty = tile / ntx, tx = tile - ty * ntx;
+  const size_t npix = (size_t)W * H;
+  for (int p = threadIdx.x; p < tw * th; p += blockDim.x) {
+    const int i = tx * tw + p % tw, j = ty * th + p / tw;
+    if (i >= W || j >= H) continue;
+    const size_t o = (size_t)j * W + i;
+    float4 C = out[o];
+    for (int k = 1; k < nseg; ++k) {
+      const float4 sgm = seg_out[(size_t)(k - 1) * npix + o];
+      if (use_max) {
+        C = make_float4(fmaxf(C.x, sgm.x), fmaxf(C.y, sgm.y), fmaxf(C.z, sgm.z), fmaxf(C.w, sgm.w));
+      } else {
+        const float w = 1.0f - C.w;
+        C.x = __fmaf_rn(w, sgm.x, C.x);
+        C.y = __fmaf_rn(w, sgm.y, C.y);
+        C.z = __fmaf_rn(w, sgm.z, C.z);
+        C.w = __fmaf_rn(w, sgm.w, C.w);
+      }
+    }
+    out[o] = C;
+  }
+}
+
 static void host_ray(const RenderParams &P, int i, int j, double A[3], double B[3]) {
   const smk_raycoef &rc = P.rc;
   float px = fmaf((float)i + 0.5f, rc.pxs, rc.pxl), py = fmaf((float)j + 0.5f, rc.pys, rc.pyl);
@@ -1666,6 +1750,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
   const int opt_fly = (opt_T >> 8) & 0xff;  // (developer knobs travel packed: slab_T | slab_fly << 8 | slab_ns << 16 | slab_sched << 24)
   const int opt_ns = (opt_T >> 16) & 0xff;
   const int opt_sched = (opt_T >> 24) & 0xf;  // (experiment knob: order of an XCD's tiles, see the schedule)
+  const int opt_split = aux->opt_split;       // DEPTH SEGMENTS: 0 auto (measured long tiles), 1 off, 2.. every tile in that many
   opt_T &= 0xff;
   *why = nullptr;
   if (tf_mode < 0 || tf_mode > 2) { *why = "no classification mode"; return hipErrorNotSupported; }
@@ -2014,6 +2099,12 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
           }
           aux->ticks_good_sig = aux->ticks_pending_sig;
           aux->ticks_age = 0;
+          // the pieces' own durations, and the cuts they were measured under (DEPTH SEGMENTS: the next cuts come from them)
+          if (aux->h_pticks && (int)aux->cuts_pending.size() == aux->ticks_pending_n * 10) {
+            aux->pticks_good.assign(aux->h_pticks, aux->h_pticks + (size_t)aux->ticks_pending_n * 8);
+            aux->cuts_good = aux->cuts_pending;
+          }
+          aux->recut = true;
         }
         aux->ticks_pending = false;
       }
@@ -2030,11 +2121,21 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
         aux->d_ticks = nullptr;
         aux->h_ticks = nullptr;
         aux->ticks_cap = 0;
+        if (aux->d_pticks) (void)hipFree(aux->d_pticks);
+        if (aux->h_pticks) (void)hipHostFree(aux->h_pticks);
+        aux->d_pticks = nullptr;
+        aux->h_pticks = nullptr;
         hipError_t e = hipMalloc((void **)&aux->d_ticks, (size_t)nt * 12);
         if (e != hipSuccess) return e;
         e = hipMemset(aux->d_ticks, 0, (size_t)nt * 12);
         if (e != hipSuccess) return e;
         e = hipHostMalloc((void **)&aux->h_ticks, (size_t)nt * 4, hipHostMallocDefault);
+        if (e != hipSuccess) return e;
+        e = hipMalloc((void **)&aux->d_pticks, (size_t)nt * 32);
+        if (e != hipSuccess) return e;
+        e = hipMemset(aux->d_pticks, 0, (size_t)nt * 32);
+        if (e != hipSuccess) return e;
+        e = hipHostMalloc((void **)&aux->h_pticks, (size_t)nt * 32, hipHostMallocDefault);
         if (e != hipSuccess) return e;
         aux->ticks_cap = nt;
       }
@@ -2043,13 +2144,103 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
         if (e != hipSuccess) return e;
       }
       Q.tile_ticks = aux->d_ticks;
+      Q.piece_ticks = aux->d_pticks;
       Q.ntiles = nt;
       aux->ticks_n_last = nt;
       ticks_sig_now = tsig;
       ticks_n_now = nt;
-      const int slots = (nw + nl) | (opt_sched << 8);  // (part of the cached plan.s key)
-      std::vector<int> order;
-      if (aux->plan_slots == slots && aux->plan_work == work && !aux->plan_order.empty()) {
+      const int slots = (nw + nl) | (opt_sched << 8) | (opt_split << 12);  // (part of the cached plan.s key)
+      std::vector<int2> order;
+      // DEPTH SEGMENTS: how many workgroups render each tile.  From MEASURED durations only (the geometric estimate says
+      // nothing about what a tile's samples cost): a tile longer than half the mean load of a workgroup slot is cut so that
+      // no piece is; tiles under 60 us are never cut (a segment costs its own set-up, ~13 us).  Small scenes therefore run
+      // unsplit, bit-identical to the gather kernel; option "slab_split" 1 turns it off, 2.. forces that many everywhere.
+      // cuts[t] = {pieces K, cut_0 = 0, ..., cut_K = 255}: the tile's slice positions in 255ths
+      const bool measured = aux->ticks_good_sig == tsig && (int)aux->ticks_good.size() == nt;
+      if ((int)aux->cuts.size() != nt * 10 || aux->cuts_split != opt_split || aux->cuts_sig != tsig) {
+        aux->cuts.assign((size_t)nt * 10, 0);
+        for (int t = 0; t < nt; ++t) { aux->cuts[(size_t)t * 10] = 1; aux->cuts[(size_t)t * 10 + 2] = 255; }
+        aux->cuts_split = opt_split;
+        aux->cuts_sig = tsig;
+        aux->recut = true;
+      }
+      if (aux->recut) {
+        aux->recut = false;
+        auto equal_cuts = [&](int t, int K) {
+          unsigned char *c = &aux->cuts[(size_t)t * 10];
+          c[0] = (unsigned char)K;
+          for (int k = 0; k <= K; ++k) c[1 + k] = (unsigned char)(255 * k / K);
+        };
+        if (opt_split >= 2) {
+          for (int t = 0; t < nt; ++t) equal_cuts(t, std::min(opt_split, 8));
+        } else if (opt_split == 0 && measured && P.blend != SMK_BLEND_BACK_TO_FRONT) {
+          long long total = 0;
+          for (int t = 0; t < nt; ++t) total += work[t];
+          const double wg_slots = 256.0 * ((nw + nl) > SLAB_BIG_WAVES ? 1 : 2);
+          // a piece should take about half the mean load of a workgroup slot, never under 60 us (a piece costs its own
+          // set-up, ~13 us); frames whose slots carry under 50 us each -- small scenes -- are not cut at all
+          // ... and only frames whose longest tile stands well above the mean load of a slot: where the slots' summed load is
+          // the bound (cfg 3 on one GPU: longest tile 0.52 ms, mean load 0.49 ms, frame 0.61 ms with every tile cut in two --
+          // 0.62 uncut) pieces only add their set-up; on a shard of 1/8 of that volume (longest 0.24, mean 0.08) they are the gain
+          const double mean_load = (double)total / wg_slots;
+          double longest_tile = 0;
+          for (int t = 0; t < nt; ++t) longest_tile = std::max(longest_tile, (double)work[t]);
+          const double piece = std::max(0.75 * mean_load, 6000.0);  // 100 MHz ticks
+          bool big_frame = mean_load >= 5000.0 && longest_tile > 1.5 * mean_load;
+          if (aux->cuts_engaged && mean_load >= 5000.0 && longest_tile > 1.2 * mean_load) big_frame = true;  // (hysteresis)
+          aux->cuts_engaged = big_frame;
+          const bool have_pieces = (int)aux->pticks_good.size() == nt * 8 && (int)aux->cuts_good.size() == nt * 10;
+          for (int t = 0; t < nt; ++t) {
+            unsigned char *c = &aux->cuts[(size_t)t * 10];
+            int Kw = (big_frame && (double)work[t] > 1.25 * piece) ? (int)std::min(8.0, ceil((double)work[t] / piece)) : 1;
+            if (big_frame && c[0] >= 2 && Kw >= 1 && abs(Kw - (int)c[0]) <= 1 && (double)work[t] > piece) Kw = c[0];  // (a tile keeps its count while the wish is a neighbour of it)
+            if (Kw == 1) { equal_cuts(t, 1); continue; }
+            // the pieces this tile was last measured in: work per 255th of depth, piecewise constant
+            const unsigned char *g = have_pieces ? &aux->cuts_good[(size_t)t * 10] : nullptr;
+            const int Kg = g ? g[0] : 1;
+            if (!g || Kg < 2) {
+              if (c[0] != Kw) equal_cuts(t, Kw);
+              continue;
+            }
+            double d[8], tot = 0, longest = 0;
+            for (int k = 0; k < Kg; ++k) {
+              d[k] = std::max(1.0, (double)aux->pticks_good[(size_t)t * 8 + k] - 1300.0);  // (less the piece's own set-up)
+              tot += d[k];
+              longest = std::max(longest, d[k]);
+            }
+            const bool same = !memcmp(g, c, 10);
+            if (same && Kg == Kw && longest <= 1.3 * tot / Kg) continue;  // balanced enough: keep (no flip-flopping)
+            // new cuts: equal shares of the measured cumulative work
+            unsigned char nc[10] = {(unsigned char)Kw, 0};
+            int k = 0;
+            double acc = 0;  // work before piece k
+            for (int j = 1; j < Kw; ++j) {
+              const double want = tot * j / Kw;
+              while (k < Kg - 1 && acc + d[k] < want) acc += d[k++];
+              const double f = d[k] > 0 ? (want - acc) / d[k] : 0.5;
+              int x = (int)lround(g[1 + k] + f * (g[2 + k] - g[1 + k]));
+              x = std::max(x, (int)nc[j] + 1);
+              x = std::min(x, 255 - (Kw - j));
+              nc[1 + j] = (unsigned char)x;
+            }
+            nc[1 + Kw] = 255;
+            memcpy(c, nc, 10);
+          }
+        } else {
+          for (int t = 0; t < nt; ++t) equal_cuts(t, 1);
+        }
+      }
+      std::vector<unsigned char> ksplit((size_t)nt, 1);
+      for (int t = 0; t < nt; ++t) ksplit[t] = aux->cuts[(size_t)t * 10];
+      // a piece's weight: its own measured duration when it was measured under these very cuts, else an equal share
+      auto piece_weight = [&](int t, int k) -> int {
+        const unsigned char *c = &aux->cuts[(size_t)t * 10];
+        if ((int)aux->pticks_good.size() == nt * 8 && (int)aux->cuts_good.size() == nt * 10 && !memcmp(&aux->cuts_good[(size_t)t * 10], c, 10) &&
+            aux->pticks_good[(size_t)t * 8 + k] > 0)
+          return (int)std::min<unsigned>(aux->pticks_good[(size_t)t * 8 + k], 1u << 30);
+        return work[t] / std::max<int>(c[0], 1);
+      };
+      if (aux->plan_slots == slots && aux->plan_work == work && aux->plan_cuts == aux->cuts && !aux->plan_order.empty()) {
         order = aux->plan_order;  // same weights, same schedule (planning stays off the per-frame path)
       } else {
         long long total = 0;
@@ -2094,7 +2285,8 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
         for (int x = 0; x < 8; ++x) {
           for (int t = cut[x]; t < cut[x + 1]; ++t) run[x].push_back(seq[t]);
           if (opt_sched == 0) {
-            std::stable_sort(run[x].begin(), run[x].end(), [&](int a, int b) { return work[a] > work[b]; });
+            // (a split tile's pieces weigh a share each: they sort behind the unsplit tiles of their tile's full weight)
+            std::stable_sort(run[x].begin(), run[x].end(), [&](int a, int b) { return work[a] / ksplit[a] > work[b] / ksplit[b]; });
           } else {
             // spatially coherent dispatch: tiles that share window fringes should stream the same slices at
             // the same time on this XCD, so that the fringe is fetched from HBM once and hit in L2 after
@@ -2114,14 +2306,54 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
           }
           longest = std::max(longest, run[x].size());
         }
-        order.assign(longest * 8, -1);
+        // a run's tiles become its workgroups {tile | piece << 20 | pieces << 26, cuts}, longest first by their own weights
+        longest = 0;
+        std::vector<std::vector<std::pair<int, int2>>> items(8);
+        for (int x = 0; x < 8; ++x) {
+          for (int t : run[x]) {
+            const unsigned char *c = &aux->cuts[(size_t)t * 10];
+            for (int k = 0; k < c[0]; ++k)
+              items[x].push_back({piece_weight(t, k), make_int2(t | (k << 20) | ((int)c[0] << 26), (int)c[1 + k] | ((int)c[2 + k] << 8))});
+          }
+          if (opt_sched == 0) std::stable_sort(items[x].begin(), items[x].end(), [](const std::pair<int, int2> &a, const std::pair<int, int2> &b) { return a.first > b.first; });
+          longest = std::max(longest, items[x].size());
+        }
+        order.assign(longest * 8, make_int2(-1, 0));
         for (int x = 0; x < 8; ++x)
-          for (size_t k = 0; k < run[x].size(); ++k) order[k * 8 + x] = run[x][k];
+          for (size_t k = 0; k < items[x].size(); ++k) order[k * 8 + x] = items[x][k].second;
+        // ... followed by the list of split tiles for the merge pass (tile | pieces << 20), and their number last
+        int nsplit = 0;
+        for (int t = 0; t < nt; ++t)
+          if (ksplit[t] > 1) { order.push_back(make_int2(t | ((int)ksplit[t] << 20), 0)); ++nsplit; }
+        order.push_back(make_int2(nsplit, 0));
         aux->plan_work = work;
+        aux->plan_cuts = aux->cuts;
         aux->plan_order = order;
         aux->plan_slots = slots;
       }
-      nblocks = (int)order.size();
+      const int nsplit = order.back().x;
+      nblocks = (int)order.size() - 1 - nsplit;
+      aux->ksplit_last.assign((size_t)nt, 1);
+      for (int k = 0; k < nsplit; ++k) {
+        const int code = order[order.size() - 1 - nsplit + k].x;
+        aux->ksplit_last[code & 0xfffff] = (unsigned char)(code >> 20);
+      }
+      int maxseg = 1;
+      for (int k = 0; k < nsplit; ++k) maxseg = std::max(maxseg, order[(size_t)nblocks + k].x >> 20);
+      aux->nsplit_last = nsplit;
+      aux->nblocks_last = nblocks;
+      if (maxseg > 1) {
+        const size_t need = (size_t)(maxseg - 1) * P.W * P.H * 16;
+        if (need > aux->seg_cap) {
+          if (aux->d_seg) (void)hipFree(aux->d_seg);
+          aux->d_seg = nullptr;
+          aux->seg_cap = 0;
+          hipError_t e = hipMalloc(&aux->d_seg, need);
+          if (e != hipSuccess) return e;
+          aux->seg_cap = need;
+        }
+      }
+      Q.seg_out = (float4 *)aux->d_seg;
       if (dbg_time) {
         dbg_t[0] += dbg_scan;
         dbg_t[1] += dbg_now() - dbg_t0;
@@ -2134,7 +2366,8 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
         hipError_t e = hipEventRecord(aux->frame_ev0, s);
         if (e != hipSuccess) return e;
       }
-      if (aux->order_host != order) {  // unchanged camera: the table on the device is still right
+      auto same_order = [&]() { return aux->order_host.size() == order.size() && (order.empty() || !memcmp(aux->order_host.data(), order.data(), order.size() * sizeof(int2))); };
+      if (!same_order()) {  // unchanged camera: the table on the device is still right
         if ((int)order.size() > aux->order_cap) {
           if (aux->d_order) (void)hipFree(aux->d_order);
           aux->d_order = nullptr;
@@ -2144,10 +2377,10 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
             aux->h_order[k] = nullptr;
           }
           aux->order_cap = 0;
-          hipError_t e = hipMalloc((void **)&aux->d_order, order.size() * sizeof(int));
+          hipError_t e = hipMalloc((void **)&aux->d_order, order.size() * sizeof(int2));
           if (e != hipSuccess) return e;
           for (int k = 0; k < 4; ++k) {
-            e = hipHostMalloc((void **)&aux->h_order[k], order.size() * sizeof(int), hipHostMallocDefault);
+            e = hipHostMalloc((void **)&aux->h_order[k], order.size() * sizeof(int2), hipHostMallocDefault);
             if (e != hipSuccess) return e;
           }
           aux->order_cap = (int)order.size();
@@ -2165,8 +2398,8 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
           hipError_t e = hipEventSynchronize(aux->order_ev[k]);
           if (e != hipSuccess) return e;
         }
-        memcpy(aux->h_order[k], order.data(), order.size() * sizeof(int));
-        hipError_t e = hipMemcpyAsync(aux->d_order, aux->h_order[k], order.size() * sizeof(int), hipMemcpyHostToDevice, s);
+        memcpy(aux->h_order[k], order.data(), order.size() * sizeof(int2));
+        hipError_t e = hipMemcpyAsync(aux->d_order, aux->h_order[k], order.size() * sizeof(int2), hipMemcpyHostToDevice, s);
         if (e != hipSuccess) return e;
         e = hipEventRecord(aux->order_ev[k], s);
         if (e != hipSuccess) return e;
@@ -2192,10 +2425,23 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     // developer diagnostics (option lockstep bits 2..64) live in separate instances of the f32 +
     // R8k kernels only: compiled into the product kernels they cost SGPRs (spills) in every frame
     const bool diag = (P.lockstep & ~1) != 0 && dtype == 1 && shade_kind == 1;
+    const int nsplit_now = aux->nsplit_last, nblocks_now = aux->nblocks_last;
+    if (nsplit_now > 0) {  // (their tick words are sums over the pieces)
+      hipError_t e = hipMemsetAsync(aux->d_ticks, 0, (size_t)ticks_n_now * 12, s);
+      if (e != hipSuccess) return e;
+    }
+    const int mtw = tw, mth = th;
     auto after_launch = [&](hipError_t e) -> hipError_t {
+      if (e == hipSuccess && nsplit_now > 0) {
+        hipLaunchKernelGGL(smk_k_slab_merge, dim3(nsplit_now), dim3(256), 0, s, (const int2 *)aux->d_order + nblocks_now, mtw, mth, P.ntx, P.W, P.H,
+                           (const float4 *)aux->d_seg, P.out, P.blend == SMK_BLEND_MAX ? 1 : 0);
+        e = hipGetLastError();
+      }
       if (e != hipSuccess || aux->ticks_pending) return e;
       // fetch this frame's per-tile durations (one copy in flight at a time)
       hipError_t e2 = hipMemcpyAsync(aux->h_ticks, aux->d_ticks, (size_t)ticks_n_now * 4, hipMemcpyDeviceToHost, s);
+      if (e2 == hipSuccess && nsplit_now > 0) e2 = hipMemcpyAsync(aux->h_pticks, aux->d_pticks, (size_t)ticks_n_now * 32, hipMemcpyDeviceToHost, s);
+      if (nsplit_now > 0) aux->cuts_pending = aux->cuts; else aux->cuts_pending.clear();
       if (e2 == hipSuccess) e2 = hipEventRecord(aux->ticks_ev, s);
       if (e2 != hipSuccess) return e2;
       aux->ticks_pending = true;
