@@ -551,8 +551,10 @@ def main():
         def repair(frame_id, ptr, stream):
             """a frame the slice-ring kernel flagged is rendered again by the gather kernel, on this rank
             alone, before its layer is exchanged"""
-            if not r.frame_failed(frame_id):
+            if r.frame_failed(frame_id) != 1:
                 return False
+            # (the benchmark's pose is static: a host whose camera moves sets frame i's camera again here, before the
+            #  re-render -- the merge itself keeps the visibility order taken when the frame was first rendered)
             r.set_option("kernel", 1)
             r.render_device(ptr, None, stream)
             torch.cuda.synchronize()

@@ -156,8 +156,12 @@ int smk_render_device(smk_ctx *ctx, void *d_rgba, void *d_depth, void *stream);
  * through a per-frame status word.  smk_last_frame_id: id of the frame the last smk_render_device call
  * enqueued (1, 2, ...).  smk_frame_failed: call after synchronising with that frame's stream; 1 = the
  * frame was flagged and must be rendered again (option "kernel" = 1 renders it on the gather kernel),
- * 0 = valid.  Answers for the last 8 frames.  A flagged frame nobody asked about makes the NEXT render
- * call fail; the synchronous smk_render re-renders such a frame itself.  Both are counted
+ * 0 = valid, -1 = unknown (never enqueued, or older than the last 8 frames).  Asking consumes the answer.
+ * The host may enqueue frame i + 1 before it asks about frame i (the pipelined protocol of the sort-last
+ * merge): a render call only looks at the status slot it takes over -- a flagged frame nobody asked
+ * about while it could be asked about makes the render call 8 frames later fail.  The synchronous
+ * smk_render re-renders a flagged frame itself.  Status words carry their frame's id, so a word that
+ * arrives after its slot was handed on is not blamed on the younger frame.  All of it is counted
  * (smk_get_stat "slab_failures" / "slab_retries") so a test or a benchmark can require zero. */
 long long smk_last_frame_id(smk_ctx *ctx);
 int smk_frame_failed(smk_ctx *ctx, long long frame_id);
@@ -194,6 +198,11 @@ const char *smk_exchange_last_error(smk_exchange *x); /* x may be NULL: last smk
 void *smk_exchange_partial(smk_exchange *x, int slot);
 int smk_exchange_acquire(smk_exchange *x, int slot, void *render_stream);
 int smk_exchange_rendered(smk_exchange *x, int slot, void *render_stream);
+/* The shards' visibility order of the frame in `slot` is taken from the context's camera at the first
+ * smk_exchange_rendered after smk_exchange_acquire -- i.e. under the pose the frame was rendered with, not the one current
+ * when the merge is enqueued; a host that knows better (a frame re-rendered later, a replayed sequence) sets it itself:
+ * order[nranks], front to back (smk_shard_order's convention). */
+int smk_exchange_set_order(smk_exchange *x, int slot, const int *order);
 int smk_exchange_frame(smk_exchange *x, int slot, void *d_frame);
 int smk_exchange_frame_local(smk_exchange *const *all, int nranks, int slot, void *d_frame);
 int smk_exchange_wait(smk_exchange *x, void *stream);
@@ -265,7 +274,14 @@ int smk_get_brick_flags(smk_ctx *ctx, unsigned char *flags_out, int *nb_out, int
 /* options (all optional; defaults in brackets):
  *   "kernel"   [0] 0 auto: both ray-marchers produce bit-identical frames, the first frames of a new
  *              configuration time one and the other and the faster is kept; 1 gather kernel (every
- *              mode); 2 slice-ring kernel (fails where it does not apply, with the reason)
+ *              mode); 2 slice-ring kernel (fails where it does not apply, with the reason); 3 column-stream
+ *              kernel (smk_cols.hip: the volume re-laid out in columns with their halo, streamed sequentially,
+ *              a ray's per-column partial composites merged in order -- the same samples, the blend
+ *              re-associated: <= 2e-5 from the other two; fails where it does not apply)
+ *   "slab_split" [0] depth segments of the slice-ring kernel: 0 = tiles measured long are rendered by several
+ *              workgroups where the longest tile stands above the mean load of a workgroup slot (sharded
+ *              contexts), the partial frames merged in order (<= 2e-5 from the unsplit frame); 1 = never
+ *              (bit-identical to the gather kernel everywhere); 2..8 = every tile in that many
  *   "tf_raw"   [0] 1: the 2-D table handed to smk_set_tf2d is already opacity-corrected (copyScale off)
  *   "halo"     [1] voxels of halo kept around a shard's region (before smk_upload_volume)
  *   "bricks"   [1] empty-space skipping: 8x8x8-cell bricks in which no sample can be visible under the current

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "smk_timing_reset", "smk_timing_read", "smk_last_frame_id", "smk_frame_failed",
     "smk_exchange_unique_id", "smk_exchange_create", "smk_exchange_connect_local", "smk_exchange_destroy",
     "smk_exchange_last_error", "smk_exchange_partial", "smk_exchange_acquire", "smk_exchange_rendered", "smk_exchange_frame",
-    "smk_exchange_frame_local", "smk_exchange_wait",
+    "smk_exchange_frame_local", "smk_exchange_wait", "smk_exchange_set_order",
 ]
 
 # gluvvDataMode order (gluvv.h:221-235)
@@ -166,6 +166,7 @@ def load_library():
     L.smk_exchange_partial.argtypes = [C.c_void_p, C.c_int]
     L.smk_exchange_acquire.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.smk_exchange_rendered.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.smk_exchange_set_order.argtypes = [C.c_void_p, C.c_int, P(C.c_int)]
     L.smk_exchange_frame.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.smk_exchange_frame_local.argtypes = [P(C.c_void_p), C.c_int, C.c_int, C.c_void_p]
     L.smk_exchange_wait.argtypes = [C.c_void_p, C.c_void_p]
@@ -379,8 +380,9 @@ class Renderer:
         return int(self.L.smk_last_frame_id(self.ctx))
 
     def frame_failed(self, frame_id):
-        """after synchronising with that frame: True = the slice-ring kernel flagged it, render it again"""
-        return bool(self.L.smk_frame_failed(self.ctx, int(frame_id)))
+        """after synchronising with that frame: 1 = a streaming kernel flagged it, render it again; 0 = valid; -1 = unknown
+        (never enqueued, or older than the status ring)"""
+        return int(self.L.smk_frame_failed(self.ctx, int(frame_id)))
 
     # -- introspection
     def raycoef(self):
@@ -502,6 +504,10 @@ class Exchange:
 
     def rendered(self, slot, render_stream=None):
         self._ck(self.L.smk_exchange_rendered(self.x, slot, render_stream))
+
+    def set_order(self, slot, order):
+        arr = (C.c_int * len(order))(*[int(v) for v in order])
+        self._ck(self.L.smk_exchange_set_order(self.x, slot, arr))
 
     def frame(self, slot, d_frame):
         self._ck(self.L.smk_exchange_frame(self.x, slot, d_frame))

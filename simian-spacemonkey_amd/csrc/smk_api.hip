@@ -495,7 +495,14 @@ extern "C" int smk_set_perturb(smk_ctx *c, const unsigned char *noise, int n, co
     return 0;
   }
   if (n < 1) FAIL(c, "smk_set_perturb: bad noise size");
-  if (dev_replace(c, &c->d_noise, noise, (size_t)n * n * n * 4)) return 1;
+  // a caller that sets the perturbation every frame (the adapter's draw()) hands over the same texture each time: the
+  // device copy is replaced -- hipFree, hipMalloc and a synchronous copy, i.e. a device synchronisation -- only when the
+  // bytes differ; weights and scales alone cost nothing
+  const size_t nbytes = (size_t)n * n * n * 4;
+  if (!(c->d_noise && c->nn == n && c->h_noise.size() == nbytes && !memcmp(c->h_noise.data(), noise, nbytes))) {
+    if (dev_replace(c, &c->d_noise, noise, nbytes)) return 1;
+    c->h_noise.assign(noise, noise + nbytes);
+  }
   c->nn = n;
   memcpy(c->pw, w, 16);
   memcpy(c->ps, s, 16);
@@ -1087,15 +1094,29 @@ extern "C" int smk_timing_read(smk_ctx *c, float *avg_ms, int *nframes) {
 // built from unloaded data silently).  Every frame has its own word, SMK_STATUS_RING of them in turn.
 // A caller that keeps frames in flight asks per frame (smk_frame_failed, after synchronising with it)
 // and renders a flagged frame again; a flag nobody asked about fails the NEXT render call loudly.
-static int take_status(smk_ctx *c, int slot) {
-  if (!c->slab.h_status) return 0;
-  const int st = ((volatile int *)c->slab.h_status)[slot];
+// The status word of frame `id` (slot id % SMK_STATUS_RING), consumed: 0 = none.  Words carry the id of the frame that wrote
+// them (a slice-ring frame may write late, into a slot that has since been handed to a younger frame): one of ANOTHER frame
+// is counted as that frame's failure and left alone for whoever owns it -- or dropped when that frame is out of the ring.
+static int take_status(smk_ctx *c, long long id) {
+  if (!c->slab.h_status || id <= 0) return 0;
+  volatile int *w = (volatile int *)c->slab.h_status + (int)(id % SMK_STATUS_RING);
+  const int st = *w;
   if (!st) return 0;
-  ((volatile int *)c->slab.h_status)[slot] = 0;
+  const long long tag = (st >> 8) & 0x7fffff;
+  if (tag != (id & 0x7fffff)) {
+    // a late word of an older frame of this slot: nobody can be told about that frame any more
+    if (((id - tag) & 0x7fffff) % SMK_STATUS_RING == 0 && tag != 0) {
+      *w = 0;
+      ++c->slab_failures;
+      ++c->slab_lost;
+    }
+    return 0;
+  }
+  *w = 0;
   ++c->slab_failures;
   // not again soon: in auto mode that configuration is the gather kernel's for a while
   if (c->opt_kernel == 0 && c->last_slab_sig) c->tune_choice[c->last_slab_sig] = {1, c->frame_id + 256};
-  return st;
+  return st & 0xff;
 }
 
 static int build_params(smk_ctx *c, RenderParams &P, hipStream_t s);
@@ -1115,11 +1136,15 @@ extern "C" int smk_get_brick_flags(smk_ctx *c, unsigned char *flags_out, int *nb
   return 0;
 }
 
-static int check_slab_status(smk_ctx *c) {
-  for (int k = 0; k < SMK_STATUS_RING; ++k) {
-    const int st = take_status(c, k);
-    if (st) FAIL(c, "%s (status %d); frame invalid", st == 1 ? "a streaming kernel reported a producer/consumer time-out" : st == 2 ? "the slice-ring kernel reported a window outside its host bound" : st == 3 ? "the column-stream kernel reported a column footprint wider than its lane lattice" : "the column-stream kernel reported a failed ray search", st);
-  }
+static const char *status_text(int st) {
+  return st == 1 ? "a streaming kernel reported a producer/consumer time-out" : st == 2 ? "the slice-ring kernel reported a window outside its host bound"
+         : st == 3 ? "the column-stream kernel reported a job whose rays do not fit its lanes or its list" : "the column-stream kernel reported a ray it cannot list";
+}
+
+// frame `id` was flagged and nobody has asked about it: the call fails
+static int check_frame_status(smk_ctx *c, long long id) {
+  const int st = take_status(c, id);
+  if (st) FAIL(c, "%s (status %d, frame %lld); frame invalid", status_text(st), st, id);
   return 0;
 }
 
@@ -1127,8 +1152,8 @@ extern "C" long long smk_last_frame_id(smk_ctx *c) { return c ? c->frame_id : 0;
 
 extern "C" int smk_frame_failed(smk_ctx *c, long long frame_id) {
   if (!c) return 1;
-  if (frame_id <= 0 || frame_id > c->frame_id || frame_id + SMK_STATUS_RING <= c->frame_id) return 0;  // unknown / too old: nothing to say
-  return take_status(c, (int)(frame_id % SMK_STATUS_RING)) ? 1 : 0;
+  if (frame_id <= 0 || frame_id > c->frame_id || frame_id + SMK_STATUS_RING <= c->frame_id) return -1;  // never enqueued, or out of the ring: unknown
+  return take_status(c, frame_id) ? 1 : 0;
 }
 
 extern "C" int smk_get_stat(smk_ctx *c, const char *name, double *value) {
@@ -1150,7 +1175,7 @@ extern "C" int smk_get_stat(smk_ctx *c, const char *name, double *value) {
     }
   if (!strcmp(name, "slab_status")) {  // status word of the latest frame (0 = ok); synchronises
     HIPCHK(c, hipDeviceSynchronize());
-    *value = c->slab.h_status ? ((volatile int *)c->slab.h_status)[c->slab.status_slot] : 0;
+    *value = c->slab.h_status ? (((volatile int *)c->slab.h_status)[c->slab.status_slot] & 0xff) : 0;
     return 0;
   }
   // frames the slice-ring kernel flagged invalid, as far as the host has looked (no synchronisation:
@@ -1497,9 +1522,13 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
   // no perturbation, rays sharing one principal axis), the generic gather kernel otherwise
   c->last_kernel = 1;
   c->slab_why.clear();
-  if (check_slab_status(c)) return 1;  // an earlier asynchronous frame was flagged and nobody asked about it (smk_frame_failed)
+  // The status word this frame takes over belongs to frame id - SMK_STATUS_RING: flagged, and nobody has asked about it
+  // (smk_frame_failed) while they could -- the call fails.  Younger frames' words are left for their owners: a host that
+  // pipelines frames asks about frame i AFTER enqueuing frame i + 1 (sortlast.Pipeline), and must find the word there.
+  if (check_frame_status(c, c->frame_id + 1 - SMK_STATUS_RING)) return 1;
   ++c->frame_id;
   c->slab.status_slot = (int)(c->frame_id % SMK_STATUS_RING);
+  c->slab.status_tag = c->cols.status_tag = (int)((c->frame_id & 0x7fffff) << 8);
   if (c->slab.h_status) ((volatile int *)c->slab.h_status)[c->slab.status_slot] = 0;
   if (c->shadow_on) {
     // ---- half-angle slicing: S launches, each the eye pass and the light pass of one slice (smk_shadow.hip)
@@ -1608,7 +1637,7 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
     HIPCHK(c, e);
     c->last_kernel = 4;
     if (c->opt_inject_status && c->slab.h_status) {
-      ((volatile int *)c->slab.h_status)[c->slab.status_slot] = c->opt_inject_status;
+      ((volatile int *)c->slab.h_status)[c->slab.status_slot] = c->slab.status_tag | c->opt_inject_status;
       c->opt_inject_status = 0;
     }
   }
@@ -1632,7 +1661,7 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
       c->last_kernel = 2;
       c->last_slab_sig = sig;
       if (c->opt_inject_status && c->slab.h_status) {  // (test hook: what a failed frame leaves behind)
-        ((volatile int *)c->slab.h_status)[c->slab.status_slot] = c->opt_inject_status;
+        ((volatile int *)c->slab.h_status)[c->slab.status_slot] = c->slab.status_tag | c->opt_inject_status;
         c->opt_inject_status = 0;
       }
     }
@@ -1686,15 +1715,15 @@ extern "C" int smk_render(smk_ctx *c, float *rgba, float *depth) {
   if (smk_render_device(c, c->d_out, depth ? c->d_depth : nullptr, c->stream)) return 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
-  if (check_slab_status(c)) {
+  if (check_frame_status(c, c->frame_id)) {
     // the synchronous entry still owes its caller this frame: in auto mode it is rendered again, by
-    // the gather kernel (check_slab_status has just retired the slice-ring kernel for this configuration)
+    // the gather kernel (take_status has just retired the slice-ring kernel for this configuration)
     if (c->opt_kernel != 0) return 1;
     const std::string first = c->err;
     ++c->slab_retries;
     if (smk_render_device(c, c->d_out, depth ? c->d_depth : nullptr, c->stream)) return 1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->last_kernel != 1 || check_slab_status(c)) {
+    if (c->last_kernel != 1 || check_frame_status(c, c->frame_id)) {
       c->err = first;
       return 1;
     }

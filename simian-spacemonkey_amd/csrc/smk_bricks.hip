@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void smk_k_brick_minmax(const void *vox, int D
   const int ex = min(BR + 1, Dx - x0), ey = min(BR + 1, Dy - y0), ez = min(BR + 1, Dz - z0);
   const int n = ex * ey * ez;
   float vmin = 3.0e38f, vmax = -3.0e38f, gmin = 3.0e38f, gmax = -3.0e38f;
+  bool bad = false;
   for (int i = lane; i < n; i += 64) {
     const int x = i % ex, y = (i / ex) % ey, z = i / (ex * ey);
     const size_t o = ((size_t)(z0 + z) * Dy + (y0 + y)) * Dx + (x0 + x);
@@ -50,18 +51,22 @@ __global__ __launch_bounds__(256) void smk_k_brick_minmax(const void *vox, int D
       v = f.x;
       g = f.y;
     }
+    // (fminf / fmaxf drop a NaN operand: a brick that mixes NaN and finite voxels would end with a finite range, while a
+    //  sample interpolated from a NaN corner classifies at base texel 0 -- possibly visible, possibly outside that range)
+    if (!(fabsf(v) <= 3.0e38f) || !(fabsf(g) <= 3.0e38f)) bad = true;
     vmin = fminf(vmin, v);
     vmax = fmaxf(vmax, v);
     gmin = fminf(gmin, g);
     gmax = fmaxf(gmax, g);
   }
+  // (a brick that saw one is stored with an inverted range: smk_k_brick_flags flags it whatever the table)
   for (int o = 32; o > 0; o >>= 1) {
     vmin = fminf(vmin, __shfl_xor(vmin, o));
     vmax = fmaxf(vmax, __shfl_xor(vmax, o));
     gmin = fminf(gmin, __shfl_xor(gmin, o));
     gmax = fmaxf(gmax, __shfl_xor(gmax, o));
   }
-  if (lane == 0) mm[brick] = make_float4(vmin, vmax, gmin, gmax);
+  if (lane == 0) mm[brick] = __any(bad) ? make_float4(1.0f, 0.0f, 1.0f, 0.0f) : make_float4(vmin, vmax, gmin, gmax);
 }
 
 // sat[(t + 1) * (sv + 1) + (s + 1)] = number of set bits (t', s') with t' <= t, s' <= s; one workgroup, a thread per
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void smk_k_brick_flags(const float4 *mm, long 
   const int pitch = sv + 1;
   const uint32_t n = sat[(size_t)(t_hi + 1) * pitch + s_hi + 1] - sat[(size_t)t_lo * pitch + s_hi + 1] -
                      sat[(size_t)(t_hi + 1) * pitch + s_lo] + sat[(size_t)t_lo * pitch + s_lo];
-  // (NaN data compares false everywhere above and ends with the full range: flagged)
+  // (a brick that holds a non-finite voxel comes with an inverted range, smk_k_brick_minmax: flagged)
   set = n != 0 || !(r.x <= r.y) || !(r.z <= r.w);
   flags[b] = set ? 1 : 0;
   }

@@ -63,7 +63,9 @@ struct ColParams {
   unsigned long long *masks;  // [npix][mask_words]
   int nkeys, mask_words;
   int use_ah, use_occ, fast_tf;
-  int *status;                // host-visible: 1 protocol time-out, 3 lattice too small for a job's footprint, 4 set-up search failed
+  int *status;                // host-visible: status_tag | (1 protocol time-out, 3 a job's rays do not fit lanes or list, 5 a ray's plane count
+                              // does not fit its list entry)
+  int status_tag;             // the frame's id << 8
   unsigned *job_ticks;        // [njobs] duration of each job's workgroup in 100 MHz ticks, or null
   unsigned long long *counts; // [8] samples taken | visible | slices streamed | segments written | consumer wave-iterations | lanes with a sample to
                               // take in them | iterations in which some lane changes rays | lanes changing rays (developer statistics)
@@ -831,7 +833,7 @@ __global__ __launch_bounds__((NW + NL) * 64) void smk_k_cols(const RenderParams 
     }
   }
   __syncthreads();
-  if (tid == 0 && ctl[0]) *(volatile int *)Q.status = ctl[0];
+  if (tid == 0 && ctl[0]) *(volatile int *)Q.status = Q.status_tag | ctl[0];
   if (tid == 0 && Q.job_ticks) {
     Q.job_ticks[job] = max((unsigned)__builtin_amdgcn_s_memrealtime() - t_begin, 1u);
     Q.job_ticks[gridDim.x + job] = t_setup - t_begin;   // (developer statistics: the set-up's share, rays listed)
@@ -1212,6 +1214,7 @@ hipError_t smk_launch_cols(RenderParams P, int dtype, int tf_mode, int shade_kin
   Q.layers = (float4 *)aux->d_layers;
   Q.masks = (unsigned long long *)aux->d_masks;
   Q.status = status_word;
+  Q.status_tag = aux->status_tag;
   Q.job_ticks = aux->d_ticks;
   Q.counts = aux->want_counts ? aux->d_counts : nullptr;
   if (Q.counts) {

@@ -87,6 +87,10 @@ struct smk_exchange {
   float4 *tile[2] = {nullptr, nullptr};        // [tp] the finished tile
   hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_sent[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
   bool used[2] = {false, false};
+  // visibility order of the ranks for the frame in each slot, taken when the frame was RENDERED (smk_exchange_rendered): the
+  // merge is enqueued a frame later, when the context's camera is already the next frame's
+  int order[2][SMK_MAX_RANKS] = {};
+  bool order_valid[2] = {false, false};
   std::string err;
   int cnt(int r) const {  // pixels of tile r that exist (the last tile may be short)
     const long long left = (long long)npix - (long long)r * tp;
@@ -232,9 +236,20 @@ extern "C" void *smk_exchange_partial(smk_exchange *x, int slot) { return x && s
 // before rendering into partial(slot) again: the frame that used it two frames ago must have been sent
 extern "C" int smk_exchange_acquire(smk_exchange *x, int slot, void *render_stream) {
   if (!x || slot < 0 || slot > 1) return 1;
+  x->order_valid[slot] = false;  // a new frame goes into the slot: its order is taken at smk_exchange_rendered
   if (!x->used[slot]) return 0;
   XHIP(x, hipSetDevice(x->ctx->device));
   XHIP(x, hipStreamWaitEvent(render_stream ? (hipStream_t)render_stream : x->ctx->stream, x->ev_sent[slot], 0));
+  return 0;
+}
+
+extern "C" int smk_exchange_set_order(smk_exchange *x, int slot, const int *order) {
+  if (!x || slot < 0 || slot > 1 || !order) return 1;
+  for (int r = 0; r < x->nranks; ++r) {
+    if (order[r] < 0 || order[r] >= x->nranks) XFAIL(x, "smk_exchange_set_order: order[%d] = %d out of range", r, order[r]);
+    x->order[slot][r] = order[r];
+  }
+  x->order_valid[slot] = true;
   return 0;
 }
 
@@ -245,13 +260,20 @@ extern "C" int smk_exchange_rendered(smk_exchange *x, int slot, void *render_str
   XHIP(x, hipSetDevice(x->ctx->device));
   // (NULL = the context's own stream, as in smk_render_device)
   XHIP(x, hipEventRecord(x->ev_in[slot], render_stream ? (hipStream_t)render_stream : x->ctx->stream));
+  // the shards' visibility order under the camera the frame was rendered with -- once per frame: a second mark of the
+  // same slot (the host re-rendered a flagged frame, possibly after setting the next pose) keeps the first one's
+  if (!x->order_valid[slot]) {
+    if (smk_shard_order(x->ctx, x->order[slot])) XFAIL(x, "smk_exchange_rendered: %s", x->ctx->err.c_str());
+    x->order_valid[slot] = true;
+  }
   return 0;
 }
 
 // this rank's layers of its own tile, in visibility order, -> the finished tile
 static int merge_tile(smk_exchange *x, int slot) {
   int order[SMK_MAX_RANKS];
-  if (smk_shard_order(x->ctx, order)) XFAIL(x, "smk_exchange: %s", x->ctx->err.c_str());
+  if (x->order_valid[slot]) memcpy(order, x->order[slot], sizeof order);
+  else if (smk_shard_order(x->ctx, order)) XFAIL(x, "smk_exchange: %s", x->ctx->err.c_str());  // (a frame nobody marked: the current camera)
   if (smk_composite_over_device(x->ctx, x->recv[slot], x->nranks, order, x->tp, x->tile[slot], x->xs))
     XFAIL(x, "smk_exchange: %s", x->ctx->err.c_str());
   return 0;

@@ -75,6 +75,7 @@ struct RenderParams {
 struct SlabAux {
   int *h_status = nullptr;      // pinned, device-visible: SMK_STATUS_RING error words (0 = ok), one per frame in turn
   int status_slot = 0;          // the word of the frame being launched
+  int status_tag = 0;           // ... and that frame's id << 8, which the kernel writes with its status
   hipEvent_t frame_ev0 = nullptr;  // recorded by the launcher right before its first stream operation
   float *d_diag = nullptr;      // [16] diagnostic counters (option lockstep bit 16)
   int2 *d_order = nullptr;      // workgroup schedule of the current camera
@@ -143,6 +144,7 @@ struct ColsAux {
   int last = 0;                 // CW | CH << 8 | nslots << 16 | shape << 24 of the latest launch
   double last_stream_bytes = 0; // bytes the loaders of the latest launch had to stream
   hipEvent_t frame_ev0 = nullptr;
+  int status_tag = 0;           // the frame's id << 8 (written with a status word)
 };
 void smk_cols_free(ColsAux *aux);
 void smk_cols_drop_layouts(ColsAux *aux);
@@ -252,6 +254,7 @@ struct smk_ctx {
 
   // perturbation
   uint32_t *d_noise = nullptr;
+  std::vector<unsigned char> h_noise;  // what d_noise holds (smk_set_perturb replaces the device copy only when the bytes change)
   int nn = 0;
   float pw[4] = {0, 0, 0, 0}, ps[4] = {0, 0, 0, 0};
 
@@ -276,6 +279,7 @@ struct smk_ctx {
   // and the faster one is kept for that configuration
   long long frame_id = 0;                  // frames enqueued so far (smk_last_frame_id)
   long long slab_failures = 0, slab_retries = 0;  // slice-ring frames flagged invalid / re-rendered by smk_render
+  long long slab_lost = 0;  // ... of which flagged too late for anybody to be told (their status slot had been handed on)
   struct TuneEntry { int kernel; long long expires; };  // (a measured or forced choice is re-examined after a while)
   std::map<unsigned long long, TuneEntry> tune_choice;
   unsigned long long last_slab_sig = 0;  // configuration of the latest slice-ring launch (a failed one is not tried again)

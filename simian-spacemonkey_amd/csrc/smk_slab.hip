@@ -72,7 +72,8 @@ struct SlabParams {
                                // slices its loaders streamed | slices of its range (the loaders stop once every ray of
                                // the tile is saturated: what was NOT streamed is not counted as read, smk_last_frame_info)
   int ntiles;
-  int *status;                 // host-visible word: 1 = protocol time-out, 2 = window bound violated
+  int *status;                 // host-visible word: status_tag | (1 = protocol time-out, 2 = window bound violated)
+  int status_tag;              // the frame's id << 8: a word written late, into a slot that has been handed on, is told apart by it
   float *diag;                 // [16] diagnostic counters (lockstep bit 16) or null
   unsigned *trace;             // [nblocks][8] per-workgroup timeline record (lockstep bit 32, see smk.h) or null
   float4 *seg_out;             // [maxseg - 1][W * H]: partial frames of the depth segments 1.. of split tiles (DEPTH SEGMENTS), or null
@@ -1423,7 +1424,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   // errors are reported, never swallowed: the host turns a non-zero status into a failed frame
   if (npos > 0) {
     __syncthreads();
-    if (tid == 0 && ctl[3]) *(volatile int *)Q.status = ctl[3];
+    if (tid == 0 && ctl[3]) *(volatile int *)Q.status = Q.status_tag | ctl[3];
   }
   if (tid == 0 && Q.tile_ticks && nseg > 1) {  // (a split tile's words are sums over its workgroups; zeroed by the launcher)
     const unsigned dur = max((unsigned)__builtin_amdgcn_s_memrealtime() - trace_t0, 1u);
@@ -1773,6 +1774,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
   SlabParams Q;
   memset(&Q, 0, sizeof Q);
   Q.status = aux->h_status + aux->status_slot;
+  Q.status_tag = aux->status_tag;
   Q.diag = aux->d_diag;
   Q.as = as;
   if (as == 2) { Q.perm = 0; Q.au = 0; Q.av = 1; }

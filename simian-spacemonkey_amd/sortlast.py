@@ -197,7 +197,9 @@ class ExchangePipeline:
         st = torch.cuda.current_stream().cuda_stream
         self.x.acquire(slot, st)
         token = self.render(self.x.partial(slot), st)
-        self.x.rendered(slot, st)
+        self.x.rendered(slot, st)      # (also takes the shards' visibility order under THIS frame's camera)
+        if order is not None:
+            self.x.set_order(slot, order)
         ev = torch.cuda.Event()
         ev.record()
         prev, self.pending = self.pending, (slot, token, ev, out)

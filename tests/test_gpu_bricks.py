@@ -247,3 +247,29 @@ def test_a_table_edited_every_frame_without_synchronising(R):
     R.set_option("kernel", 0)
     R.set_option("bricks", 1)
     push_scene(R, sc)
+
+
+def test_a_nan_voxel_keeps_its_brick_flagged(R):
+    """fminf / fmaxf drop a NaN operand: a brick that mixes one NaN voxel with values the table leaves transparent would
+    get a finite, 'empty' range, while a sample interpolated from the NaN corner classifies at base texel 0 -- which this
+    table makes opaque.  A brick that saw a non-finite voxel is flagged whatever the table: frames with and without the
+    flags stay bit-identical, on both kernels."""
+    import oracle as O
+    sc = make_scene("cfg3", n=32, size=64, steps=64, pose="rot", f32=True, shade=0)
+    data = np.full(sc.data.shape, 0.9, np.float32)        # everything up here, where the table below is transparent
+    data[12, 13, 14, 0] = np.nan
+    data[20, 5, 7, 1] = np.inf
+    sc = O.Scene(data, grad=sc.grad)
+    sc.tf_mode = 1
+    tf = np.zeros((256, 256, 4), np.uint8)
+    tf[:4, :4] = (255, 200, 100, 255)                     # texel (0, 0) and its neighbours: opaque
+    sc.tf_vg = tf
+    sc.width = sc.height = 64
+    sc.steps = 64
+    sc.xform = O.rotation((1, 1, 0), 30)
+    g, s0, s1, f0, f1 = _three(R, sc)
+    assert np.array_equal(np.nan_to_num(s0, nan=-1.0), np.nan_to_num(g, nan=-1.0))
+    assert np.array_equal(np.nan_to_num(s1, nan=-1.0), np.nan_to_num(g, nan=-1.0))
+    flags, nb, in_use = R.brick_flags()
+    assert in_use and flags.reshape(nb[::-1])[12 // 8, 13 // 8, 14 // 8] == 1 and flags.reshape(nb[::-1])[20 // 8, 5 // 8, 7 // 8] == 1
+    assert flags.sum() < flags.size                        # (the finite rest is not flagged)

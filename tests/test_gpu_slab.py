@@ -364,20 +364,31 @@ def test_a_failed_slice_ring_frame_is_rendered_again_and_not_tried_twice(gpu_ren
         with pytest.raises(Exception, match="time-out"):
             r.render()
         assert np.abs(r.render() - ref).max() <= TOL         # the next forced frame is fine
-        # asynchronous entry: the failure surfaces at the next call, after which auto mode uses the gather kernel
+        # asynchronous entry: the host asks about the frame (smk_frame_failed), after which auto mode uses the gather kernel
         sc.steps = 65                                        # a new configuration
         push_scene(r, sc, upload=False)
         r.set_option("kernel", 0)
         out = torch.zeros((64 * 64, 4), dtype=torch.float32, device="cuda")
         r.set_option("inject_slab_status", 2)
         r.render_device(out.data_ptr(), None, None)          # first trial frame = slice-ring kernel
+        bad = r.last_frame_id()
+        torch.cuda.synchronize()
+        assert r.frame_failed(bad) == 1
+        r.render_device(out.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        assert r.last_frame_info()[0] == 1
+        assert np.abs(out.cpu().numpy().reshape(64, 64, 4) - sc.render()).max() <= TOL
+        # ... and a flagged frame nobody asks about fails the call that takes over its status slot, eight frames on
+        r.set_option("kernel", 2)
+        r.set_option("inject_slab_status", 2)
+        r.render_device(out.data_ptr(), None, None)
+        for _ in range(7):
+            r.render_device(out.data_ptr(), None, None)
         torch.cuda.synchronize()
         with pytest.raises(Exception, match="window outside"):
             r.render_device(out.data_ptr(), None, None)
         r.render_device(out.data_ptr(), None, None)
         torch.cuda.synchronize()
-        assert r.last_frame_info()[0] == 1
-        assert np.abs(out.cpu().numpy().reshape(64, 64, 4) - sc.render()).max() <= TOL
     finally:
         r.close()
 
@@ -402,8 +413,9 @@ def test_frames_in_flight_report_their_own_status(gpu_renderer_factory):
         assert b == a + 1
         torch.cuda.synchronize()
         assert r.stat("slab_failures") == 1                   # seen without being consumed
-        assert not r.frame_failed(a) and r.frame_failed(b)
-        assert not r.frame_failed(b)                          # asked and answered
+        assert r.frame_failed(a) == 0 and r.frame_failed(b) == 1
+        assert r.frame_failed(b) == 0                         # asked and answered
+        assert r.frame_failed(b + 5) == -1 and r.frame_failed(0) == -1   # never enqueued: unknown, not "valid"
         r.set_option("kernel", 1)
         r.render_device(out[1].data_ptr(), None, None)        # the repair: no error from the earlier frame
         torch.cuda.synchronize()
@@ -478,3 +490,33 @@ def test_depth_segments_few_planes_and_max_blend(R):
         R.set_blend(0)
         R.set_option("slab_split", 0)
         R.set_option("kernel", 0)
+
+
+def test_a_pipelining_host_asks_about_frame_i_after_enqueuing_frame_i_plus_1(gpu_renderer_factory):
+    """The sort-last pipeline's order of calls: render(i), render(i + 1), then frame_failed(i).  The second render call
+    must not consume (or trip over) frame i's status word -- it only looks at the slot it takes over -- so the host still
+    learns that frame i was flagged, repairs it locally, and no rank is left waiting in a collective."""
+    import torch
+    r = gpu_renderer_factory()
+    try:
+        sc = make_scene("cfg3", n=32, size=64, steps=64, pose="rot", f32=True, shade=1)
+        ref = sc.render()
+        push_scene(r, sc)
+        r.set_option("kernel", 2)
+        out = torch.zeros((2, 64 * 64, 4), dtype=torch.float32, device="cuda")
+        r.set_option("inject_slab_status", 1)
+        r.render_device(out[0].data_ptr(), None, None)        # frame i, flagged
+        i = r.last_frame_id()
+        torch.cuda.synchronize()                              # (its word has landed by the time the next call is made)
+        r.render_device(out[1].data_ptr(), None, None)        # frame i + 1: must not raise
+        assert r.last_frame_id() == i + 1
+        torch.cuda.synchronize()
+        assert r.frame_failed(i) == 1 and r.frame_failed(i + 1) == 0
+        r.set_option("kernel", 1)
+        r.render_device(out[0].data_ptr(), None, None)        # the repair
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert np.abs(out[k].cpu().numpy().reshape(64, 64, 4) - ref).max() <= TOL
+        assert r.stat("slab_failures") == 1
+    finally:
+        r.close()

@@ -169,3 +169,47 @@ def test_exchange_rccl_transport_loads_and_runs_a_single_rank(gpu_renderer_facto
         if x is not None:
             x.close()
         R.close()
+
+
+def test_merge_uses_the_order_of_the_pose_the_frame_was_rendered_with(gpu_renderer_factory, smk):
+    """Frame i's merge is enqueued after frame i + 1's camera has been set (two frames in flight).  When the eye crosses
+    the shards' split plane between the two poses the visibility orders differ, and "over" is not commutative: the merge
+    must use the order taken when frame i was rendered (smk_exchange_rendered), not the context's current camera."""
+    import torch
+    world = 2
+    a = make_scene("cfg3", n=32, size=48, steps=48, pose="rot", f32=True, shade=1)
+    b = make_scene("cfg3", n=32, size=48, steps=48, pose="rot", f32=True, shade=1)
+    a.xform = __import__("oracle").rotation((0, 1, 0), 35)      # eye on one side of the x mid-plane ...
+    b.xform = __import__("oracle").rotation((0, 1, 0), -35)     # ... and on the other
+    npix = a.width * a.height
+    rs, xs = [], []
+    try:
+        for r in range(world):
+            R = gpu_renderer_factory()
+            rs.append(R)
+            R.set_shard(r, world)
+            push_scene(R, a)
+            xs.append(smk.binding.Exchange(R, r, world, npix))
+        smk.binding.Exchange.connect_local(xs)
+        orders = []
+        for sc in (a, b):
+            push_scene(rs[0], sc, upload=False)
+            orders.append(rs[0].shard_order(world))
+        assert orders[0] != orders[1], "the two poses must see the shards in different orders"
+        frame = torch.zeros((npix, 4), dtype=torch.float32, device="cuda")
+        for R, x in zip(rs, xs):
+            push_scene(R, a, upload=False)
+            x.acquire(0)
+            R.render_device(x.partial(0), None, None)
+            x.rendered(0)
+            push_scene(R, b, upload=False)                        # the next frame's pose, before this frame's merge
+        smk.binding.Exchange.frame_local(xs, 0, frame.data_ptr())
+        xs[0].wait(None)
+        torch.cuda.synchronize()
+        got = frame.cpu().numpy().reshape(a.height, a.width, 4)
+        assert np.abs(got - a.render()).max() <= 1e-4
+    finally:
+        for x in xs:
+            x.close()
+        for R in rs:
+            R.close()
