@@ -270,6 +270,6 @@ def test_a_nan_voxel_keeps_its_brick_flagged(R):
     g, s0, s1, f0, f1 = _three(R, sc)
     assert np.array_equal(np.nan_to_num(s0, nan=-1.0), np.nan_to_num(g, nan=-1.0))
     assert np.array_equal(np.nan_to_num(s1, nan=-1.0), np.nan_to_num(g, nan=-1.0))
-    flags, nb, in_use = R.brick_flags()
-    assert in_use and flags.reshape(nb[::-1])[12 // 8, 13 // 8, 14 // 8] == 1 and flags.reshape(nb[::-1])[20 // 8, 5 // 8, 7 // 8] == 1
+    flags, in_use = R.brick_flags()                         # [z][y][x] of bricks
+    assert in_use and flags[12 // 8, 13 // 8, 14 // 8] == 1 and flags[20 // 8, 5 // 8, 7 // 8] == 1
     assert flags.sum() < flags.size                        # (the finite rest is not flagged)
