@@ -415,8 +415,14 @@ def extra_legs(r, frame, work, steps):
     r.set_sampling(0.0, 1024, 1.0, 1)
     r.set_shading("r8k", LIGHT, EYE, AT, xf, INTENS)
     run("cfg5_unperturbed", 1024, 1024, "cfg5 without the perturbation: 2 x 512^3 u8 fields merged (V2G), dense 3-D table %dx%dx%d, R8k Phong, 1024x1024x1024" % (t3.shape[2], t3.shape[1], t3.shape[0]))
+    # SURVEY 8(d)'s configuration: weights (.2, .1), scales (.2, 2.1) (R8kVolRen3D_cpy.cpp:1590-1595, gluvvui.cpp:213-267) --
+    # a displacement of up to +-77 voxels at 512^3: the brick flags' reach covers the volume, every in-volume sample pays
+    # its two noise lookups
+    r.set_perturb(libc_noise_tex(32), (.2, .1, 0, 0), (.2, 2.1, 4.5, 8.7))
+    run("cfg5", 1024, 1024, "cfg5 as SURVEY 8(d) states it: noise-perturbed fetch, 32^3 noise, weights .2/.1, scales .2/2.1: gather kernel")
+    # ... and the same at a tenth of the weights (round 2's leg: displacements of +-7.7 voxels, which the flags can bracket)
     r.set_perturb(libc_noise_tex(32), (.02, .01, 0, 0), (.2, 2.1, 4.5, 8.7))
-    run("cfg5", 1024, 1024, "cfg5: the same with the noise-perturbed fetch (32^3 noise, weights .02/.01, scales .2/2.1): gather kernel")
+    run("cfg5_tenth_of_the_weights", 1024, 1024, "cfg5 with weights .02/.01 (a tenth of the stated ones; NOT the configuration SURVEY 8(d) names): gather kernel")
     r.set_perturb(None, None, None)
     r.set_option("tf_raw", 0)
     return out

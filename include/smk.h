@@ -116,6 +116,11 @@ int smk_set_sampling(smk_ctx *ctx, float sample_rate, int steps, float gamma, in
  * on one side of an axis-aligned plane through vpos (volume space, the units of fPos/fSize).
  * oaxis = VolRenMajorAxis: 1 X+ (x <= vpos.x stays), 2 X-, 3 Y+, 4 Y-, 5 Z+, 6 Z-.  on = 0: off. */
 int smk_set_clip(smk_ctx *ctx, int on, int oaxis, const float vpos[3]);
+/* replaces the extents of VolumeRenderer::renderVolume(sampleRate, mv, xext, yext, zext) (VolumeRenderer.h:103-108,
+ * VolumeRenderer.cpp:333-384, render3DVolumeEXTSV :428-505): only the axis-aligned sub-box lo..hi of the volume is drawn
+ * (volume space, the units of fPos / fSize; clamped to the volume as :452-457 do; the reference's `x[1] -= origf[1]` slip,
+ * :459, is not reproduced).  Planes stay the whole volume's.  on = 0: off. */
+int smk_set_region(smk_ctx *ctx, int on, const float lo[3], const float hi[3]);
 /* replaces the clip widget's free mode: glClipPlane(GL_CLIP_PLANE5, {0,0,-1,0}) specified under the
  * modelview wmv * T(clip.pos) * clip.xform (NV20VolRen3D.cpp:346-357; R8kVolRen3D.cpp:780-794).
  * plane_eye = the eye-space plane OpenGL stores for that call ({0,0,-1,0} times the inverse of that
@@ -150,6 +155,15 @@ int smk_set_blend(smk_ctx *ctx, smk_blend mode);
 int smk_render(smk_ctx *ctx, float *rgba_out, float *depth_out);
 /* same with DEVICE output pointers; asynchronous on `stream` (a hipStream_t, NULL = default) */
 int smk_render_device(smk_ctx *ctx, void *d_rgba, void *d_depth, void *stream);
+
+/* replaces VolumeRenderer::renderSlice(quad, alpha) (VolumeRenderer.h:114, VolumeRenderer.cpp:748-807): ONE quad (model
+ * space, the units of fPos / fSize; drawn as glBegin(GL_QUADS) with the vertices in the order 1, 0, 2, 3) textured with the
+ * scalar volume -- GL_INTENSITY8, GL_LINEAR, no colour table (:768), texture coordinates = vertex / fSize -- modulated by
+ * glColor4f(1, 1, 1, alpha) and blended GL_ONE, GL_ONE_MINUS_SRC_ALPHA into the frame:
+ *   src = (I, I, I, I * alpha), frame = src + (1 - src.a) * frame,   I = the first data channel in [0, 1].
+ * Uses the camera of smk_set_camera.  rgba_inout: [height][width][4] float, read and written. */
+int smk_render_slice(smk_ctx *ctx, const float quad[4][3], float alpha, float *rgba_inout);
+int smk_render_slice_device(smk_ctx *ctx, const float quad[4][3], float alpha, void *d_rgba_inout, void *stream);
 
 /* Frames in flight (no reference equivalent: the reference renders synchronously).  smk_render_device
  * only enqueues; the slice-ring kernel reports a protocol time-out or a window outside its host bound

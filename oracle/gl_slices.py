@@ -124,3 +124,49 @@ def render_scalar_slices(vol_u8, fsize, mv, frustum, znear, zfar, width, height,
                     img[j, i] = src + (1 - src[3]) * img[j, i]
                     break
     return img
+
+
+def render_quad_slice(img, vol01, fsize, mv, frustum, znear, zfar, quad, alpha):
+    """VolumeRenderer::render3dSliceEXT (VolumeRenderer.cpp:762-807) in float64: ONE quad in model space, vertices issued
+    1, 0, 2, 3, textured with the scalar volume (GL_INTENSITY8: (I, I, I, I), no colour table), modulated by
+    glColor4f(1, 1, 1, alpha), blended GL_ONE, GL_ONE_MINUS_SRC_ALPHA into img [H][W][4] (in place; returns the pixels
+    the quad's EDGE passes within a quarter pixel of, which a different rasteriser may decide the other way)."""
+    height, width = img.shape[:2]
+    M = np.array(mv, np.float64).reshape(4, 4).T
+    P = _frustum(frustum[0], frustum[1], frustum[2], frustum[3], znear, zfar)
+    q = np.array(quad, np.float64)[[1, 0, 2, 3]]
+    tcs = q / np.array([float(f) for f in fsize])
+    eye = (M[:3, :3] @ q.T).T + M[:3, 3]
+    clip = (P @ np.concatenate([eye, np.ones((4, 1))], axis=1).T).T
+    w = clip[:, 3]
+    ndc = clip[:, :2] / w[:, None]
+    win = np.stack([(ndc[:, 0] * .5 + .5) * width, (ndc[:, 1] * .5 + .5) * height], axis=1)
+    edge = np.zeros((height, width), bool)
+    x0, x1 = int(np.floor(win[:, 0].min())), int(np.ceil(win[:, 0].max()))
+    y0, y1 = int(np.floor(win[:, 1].min())), int(np.ceil(win[:, 1].max()))
+    for j in range(max(y0, 0), min(y1 + 1, height)):
+        for i in range(max(x0, 0), min(x1 + 1, width)):
+            p = np.array([i + .5, j + .5])
+            for k in (1, 2):
+                a, b, c = win[0], win[k], win[k + 1]
+                den = (b[1] - c[1]) * (a[0] - c[0]) + (c[0] - b[0]) * (a[1] - c[1])
+                if den == 0:
+                    continue
+                l0 = ((b[1] - c[1]) * (p[0] - c[0]) + (c[0] - b[0]) * (p[1] - c[1])) / den
+                l1 = ((c[1] - a[1]) * (p[0] - c[0]) + (a[0] - c[0]) * (p[1] - c[1])) / den
+                l2 = 1 - l0 - l1
+                scale = np.sqrt(abs(den))                    # ~ the triangle's size in pixels
+                outer = (min(l0, l2) if k == 1 else min(l1, l0)) * scale if False else None
+                if min(l0, l1, l2) < 0:
+                    if min(l0, l1, l2) * scale > -0.25:
+                        edge[j, i] = True
+                    continue
+                if min(l0, l1, l2) * scale < 0.25:
+                    edge[j, i] = True
+                iw = np.array([l0 / w[0], l1 / w[k], l2 / w[k + 1]])
+                tc = (iw[0] * tcs[0] + iw[1] * tcs[k] + iw[2] * tcs[k + 1]) / iw.sum()
+                inten = min(max(_tex3d_linear(vol01, tc[0], tc[1], tc[2]), 0.0), 1.0)
+                src = np.array([inten, inten, inten, min(max(inten * alpha, 0.0), 1.0)])
+                img[j, i] = src + (1 - src[3]) * img[j, i]
+                break
+    return edge

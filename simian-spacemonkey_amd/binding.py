@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "smk_exchange_unique_id", "smk_exchange_create", "smk_exchange_connect_local", "smk_exchange_destroy",
     "smk_exchange_last_error", "smk_exchange_partial", "smk_exchange_acquire", "smk_exchange_rendered", "smk_exchange_frame",
     "smk_exchange_frame_local", "smk_exchange_wait", "smk_exchange_set_order",
+    "smk_set_region", "smk_render_slice", "smk_render_slice_device",
 ]
 
 # gluvvDataMode order (gluvv.h:221-235)
@@ -117,6 +118,9 @@ def load_library():
     L.smk_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.smk_set_clip.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.smk_set_clip_plane.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
+    L.smk_set_region.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.smk_render_slice.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float)]
+    L.smk_render_slice_device.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.c_void_p, C.c_void_p]
     L.smk_shard_order.argtypes = [C.c_void_p, P(C.c_int)]
     L.smk_set_tlut1d.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.smk_set_tf2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -319,6 +323,20 @@ class Renderer:
             self._ck(self.L.smk_set_clip_plane(self.ctx, 0, None))
         else:
             self._ck(self.L.smk_set_clip_plane(self.ctx, 1, (C.c_double * 4)(*[float(v) for v in plane_eye])))
+
+    def set_region(self, lo=None, hi=None):
+        """sub-box of the volume in volume space (renderVolume's x/y/zext); None = off"""
+        if lo is None:
+            self._ck(self.L.smk_set_region(self.ctx, 0, None, None))
+        else:
+            self._ck(self.L.smk_set_region(self.ctx, 1, _fa(lo, 3), _fa(hi, 3)))
+
+    def render_slice(self, quad, alpha, rgba):
+        """VolumeRenderer::renderSlice: one textured quad (4 x 3, model space) blended into rgba [H][W][4] (in place)"""
+        q = np.ascontiguousarray(quad, np.float32).reshape(12)
+        assert rgba.dtype == np.float32 and rgba.flags["C_CONTIGUOUS"]
+        self._ck(self.L.smk_render_slice(self.ctx, q.ctypes.data_as(C.POINTER(C.c_float)), float(alpha), rgba.ctypes.data_as(C.POINTER(C.c_float))))
+        return rgba
 
     def set_perturb(self, noise, w, s):
         if noise is None:

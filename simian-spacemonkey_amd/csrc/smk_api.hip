@@ -6,7 +6,7 @@
 
 #include <algorithm>
 
-#include "smk_internal.h"
+#include "smk_device.h"
 
 static std::string g_create_err;
 
@@ -326,6 +326,21 @@ extern "C" int smk_set_clip(smk_ctx *c, int on, int oaxis, const float *vpos) {
   if (oaxis < 1 || oaxis > 6 || !vpos) FAIL(c, "smk_set_clip: axis must be 1..6 (X+ X- Y+ Y- Z+ Z-) and vpos given");
   c->clip_axis = oaxis;
   for (int a = 0; a < 3; ++a) c->clip_vpos[a] = vpos[a];
+  return 0;
+}
+
+extern "C" int smk_set_region(smk_ctx *c, int on, const float *lo, const float *hi) {
+  if (!c) return 1;
+  if (!on) {
+    c->region_on = 0;
+    return 0;
+  }
+  if (!lo || !hi) FAIL(c, "smk_set_region: null extents");
+  for (int a = 0; a < 3; ++a) {
+    c->region_lo[a] = lo[a] < hi[a] ? lo[a] : hi[a];
+    c->region_hi[a] = lo[a] < hi[a] ? hi[a] : lo[a];
+  }
+  c->region_on = 1;
   return 0;
 }
 
@@ -1331,6 +1346,17 @@ static int build_params(smk_ctx *c, RenderParams &P, hipStream_t s) {
       P.lo[a] = face;
     }
   }
+  // sub-box of renderVolume(.., xext, yext, zext) (VolumeRenderer.cpp:428-505): the region shrinks on every axis; the new
+  // upper faces are half-open like a shard's inner ones (a face that coincides with a voxel plane belongs to one side)
+  if (c->region_on)
+    for (int a = 0; a < 3; ++a) {
+      const double fs = c->fsize[a];
+      const double l = c->region_lo[a] > 0 ? (c->region_lo[a] < fs ? c->region_lo[a] : fs) : 0.0;
+      const double h = c->region_hi[a] > 0 ? (c->region_hi[a] < fs ? c->region_hi[a] : fs) : 0.0;
+      const float flo = (float)(l / fs * (double)c->N[a] - 0.5), fhi = (float)(h / fs * (double)c->N[a] - 0.5);
+      if (flo > P.lo[a]) P.lo[a] = flo;
+      if (fhi < P.hi[a]) { P.hi[a] = fhi; P.top[a] = 0; }
+    }
   for (int a = 0; a < 3; ++a) P.hin[a] = P.top[a] ? P.hi[a] : nextafterf(P.hi[a], -INFINITY);
   // free clip plane: eye-space plane -> voxel coordinates.  eye = MV * model, model = (p + 1/2)/N * fSize
   // (same operations in the same order as the CPU checker's orc_clip_plane_voxel)
@@ -1731,6 +1757,127 @@ extern "C" int smk_render(smk_ctx *c, float *rgba, float *depth) {
   }
   HIPCHK(c, hipMemcpy(rgba, c->d_out, npix * 16, hipMemcpyDeviceToHost));
   if (depth) HIPCHK(c, hipMemcpy(depth, c->d_depth, npix * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------- renderSlice
+
+// VolumeRenderer::render3dSliceEXT (VolumeRenderer.cpp:762-807): one textured quad blended into the frame.  A thread per
+// pixel: the ray through the pixel centre against the quad's two triangles (vertices in GL's order 1, 0, 2, 3 -> (a, b, c),
+// (a, c, d)); texture coordinates are vertex / fSize, i.e. linear in the model-space position, so the perspective-correct
+// interpolation GL does IS the hit point.  Sampling as the ray-marchers do: GL_LINEAR, clamp to edge, channel 0.
+struct SliceArg {
+  float v[4][3];   // quad vertices in voxel coordinates (x / fSize * N - 0.5), order a, b, c, d
+  float alpha;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void smk_k_render_slice(const RenderParams P, const SliceArg Q, float4 *fb) {
+  const int i = blockIdx.x * 16 + (threadIdx.x & 15), j = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (i >= P.W || j >= P.H) return;
+  const smk_raycoef &rc = P.rc;
+  const float px = __fmaf_rn((float)i + 0.5f, rc.pxs, rc.pxl), py = __fmaf_rn((float)j + 0.5f, rc.pys, rc.pyl);
+  float A[3], B[3];
+  for (int a = 0; a < 3; ++a) {
+    A[a] = __fmaf_rn(px, rc.Ax[a], __fmaf_rn(py, rc.Ay[a], rc.Ac[a]));
+    B[a] = __fmaf_rn(px, rc.Bx[a], __fmaf_rn(py, rc.By[a], rc.Bc[a]));
+  }
+  // eye = A - (tau0 / dtau) B (every ray starts there); direction B
+  const float k = rc.tau0 / rc.dtau;
+  const float O[3] = {A[0] - k * B[0], A[1] - k * B[1], A[2] - k * B[2]};
+  bool hit = false;
+  float X[3] = {0, 0, 0};
+  for (int t = 0; t < 2 && !hit; ++t) {
+    const float *v0 = Q.v[0], *v1 = Q.v[t == 0 ? 1 : 2], *v2 = Q.v[t == 0 ? 2 : 3];
+    const float e1[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]}, e2[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+    const float pv[3] = {B[1] * e2[2] - B[2] * e2[1], B[2] * e2[0] - B[0] * e2[2], B[0] * e2[1] - B[1] * e2[0]};
+    const float det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
+    if (fabsf(det) < 1e-20f) continue;
+    const float inv = 1.0f / det;
+    const float tv[3] = {O[0] - v0[0], O[1] - v0[1], O[2] - v0[2]};
+    const float u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) * inv;
+    const float qv[3] = {tv[1] * e1[2] - tv[2] * e1[1], tv[2] * e1[0] - tv[0] * e1[2], tv[0] * e1[1] - tv[1] * e1[0]};
+    const float w = (B[0] * qv[0] + B[1] * qv[1] + B[2] * qv[2]) * inv;
+    const float tt = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) * inv;
+    if (u < 0.0f || w < 0.0f || u + w > 1.0f || !(tt * rc.dtau > 0.0f)) continue;  // (in front of the eye)
+    hit = true;
+    for (int a = 0; a < 3; ++a) X[a] = v0[a] + u * e1[a] + w * e2[a];
+  }
+  if (!hit) return;
+  int x0, x1, y0, y1, z0, z1;
+  float fx, fy, fz;
+  smk_lin_clamp(X[0], P.N[0], x0, x1, fx);
+  smk_lin_clamp(X[1], P.N[1], y0, y1, fy);
+  smk_lin_clamp(X[2], P.N[2], z0, z1, fz);
+  x0 = min(max(x0 - P.O[0], 0), P.D[0] - 1); x1 = min(max(x1 - P.O[0], 0), P.D[0] - 1);
+  y0 = min(max(y0 - P.O[1], 0), P.D[1] - 1); y1 = min(max(y1 - P.O[1], 0), P.D[1] - 1);
+  z0 = min(max(z0 - P.O[2], 0), P.D[2] - 1); z1 = min(max(z1 - P.O[2], 0), P.D[2] - 1);
+  const size_t Dx = P.D[0], Dy = P.D[1];
+  auto at = [&](int x, int y, int z) -> float { return smk_load_corner<DT>(P, ((size_t)z * Dy + y) * Dx + x).c0; };
+  float I = smk_lerp(smk_lerp(smk_lerp(at(x0, y0, z0), at(x1, y0, z0), fx), smk_lerp(at(x0, y1, z0), at(x1, y1, z0), fx), fy),
+                     smk_lerp(smk_lerp(at(x0, y0, z1), at(x1, y0, z1), fx), smk_lerp(at(x0, y1, z1), at(x1, y1, z1), fx), fy), fz);
+  if (DT == 0) I *= SMK_INV255;
+  I = smk_sat(I);
+  const float sa = smk_sat(I * Q.alpha);
+  float4 D = fb[(size_t)j * P.W + i];
+  const float w1 = 1.0f - sa;
+  D.x = __fmaf_rn(w1, D.x, I);
+  D.y = __fmaf_rn(w1, D.y, I);
+  D.z = __fmaf_rn(w1, D.z, I);
+  D.w = __fmaf_rn(w1, D.w, sa);
+  fb[(size_t)j * P.W + i] = D;
+}
+
+extern "C" int smk_render_slice_device(smk_ctx *c, const float quad[4][3], float alpha, void *d_rgba, void *stream) {
+  if (!c) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!quad || !d_rgba) FAIL(c, "smk_render_slice: null argument");
+  if (!c->have_volume) FAIL(c, "smk_render_slice: no volume uploaded");
+  if (!c->have_camera) FAIL(c, "smk_render_slice: no camera set");
+  if (c->nranks > 1) FAIL(c, "smk_render_slice: the slice quad is drawn from the whole volume (unsharded context)");
+  RenderParams P;
+  memset(&P, 0, sizeof P);
+  double inv[16];
+  compute_raycoef(c, &P.rc, inv);
+  P.vox = c->d_vox;
+  P.nrm = c->d_nrm;
+  for (int a = 0; a < 3; ++a) { P.N[a] = c->N[a]; P.O[a] = c->O[a]; P.D[a] = c->D[a]; }
+  P.nelts = c->nelts;
+  P.n_in_w = (c->dtype == SMK_F32 && c->nelts <= 3) ? 1 : 0;
+  P.W = c->W;
+  P.H = c->H;
+  SliceArg Q;
+  const int ord[4] = {1, 0, 2, 3};  // glVertex order of render3dSliceEXT (:776-792)
+  for (int k = 0; k < 4; ++k)
+    for (int a = 0; a < 3; ++a) Q.v[k][a] = (float)((double)quad[ord[k]][a] / (double)c->fsize[a] * (double)c->N[a] - 0.5);
+  Q.alpha = alpha;
+  hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+  dim3 grid((c->W + 15) / 16, (c->H + 15) / 16);
+  if (c->dtype == SMK_U8) hipLaunchKernelGGL(smk_k_render_slice<0>, grid, dim3(256), 0, s, P, Q, (float4 *)d_rgba);
+  else hipLaunchKernelGGL(smk_k_render_slice<1>, grid, dim3(256), 0, s, P, Q, (float4 *)d_rgba);
+  HIPCHK(c, hipGetLastError());
+  return 0;
+}
+
+extern "C" int smk_render_slice(smk_ctx *c, const float quad[4][3], float alpha, float *rgba) {
+  if (!c) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!rgba) FAIL(c, "smk_render_slice: null frame");
+  if (!c->have_camera) FAIL(c, "smk_render_slice: no camera set");
+  const size_t npix = (size_t)c->W * c->H;
+  if (npix > c->out_cap) {
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_depth) (void)hipFree(c->d_depth);
+    c->d_out = nullptr;
+    c->d_depth = nullptr;
+    HIPCHK(c, hipMalloc((void **)&c->d_out, npix * 16));
+    HIPCHK(c, hipMalloc((void **)&c->d_depth, npix * 4));
+    c->out_cap = npix;
+  }
+  HIPCHK(c, hipMemcpy(c->d_out, rgba, npix * 16, hipMemcpyHostToDevice));
+  if (smk_render_slice_device(c, quad, alpha, c->d_out, c->stream)) return 1;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(rgba, c->d_out, npix * 16, hipMemcpyDeviceToHost));
   return 0;
 }
 

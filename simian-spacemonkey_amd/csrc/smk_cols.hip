@@ -324,7 +324,7 @@ __global__ __launch_bounds__((NW + NL) * 64) void smk_k_cols(const RenderParams 
             for (int k = 0; k < 8 && qa <= qb && !in(qa); ++k) ++qa;
 #pragma unroll 1
             for (int k = 0; k < 8 && qa <= qb && !in(qb); ++k) --qb;
-            if (qa <= qb && (in(qa) & in(qb))) {
+            if (qa <= qb && in(qa) && in(qb)) {
               have = true;
               m_in = qa;
               m_out = qb;

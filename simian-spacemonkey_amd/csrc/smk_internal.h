@@ -182,6 +182,8 @@ struct smk_ctx {
   int g0[3] = {0, 0, 0}, g1[3] = {0, 0, 0};  // this context's region
   int O[3] = {0, 0, 0}, D[3] = {0, 0, 0};
   int halo = 1;
+  int region_on = 0;  // sub-box of renderVolume(.., xext, yext, zext): volume space
+  float region_lo[3] = {0, 0, 0}, region_hi[3] = {0, 0, 0};
   int clip_axis = 0;  // orthogonal clip plane: 0 off, 1..6 = X+ X- Y+ Y- Z+ Z-
   float clip_vpos[3] = {0, 0, 0};
   int cplane_on = 0;  // free clip plane (glClipPlane), eye space

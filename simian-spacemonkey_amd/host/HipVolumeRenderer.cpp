@@ -15,7 +15,7 @@ static void build_world_modelview(double mv[16]);
 static void mul(double o[16], const double a[16], const double b[16]);
 static void translate(double m[16], double x, double y, double z);
 
-HipVolumeRenderer::HipVolumeRenderer(MetaVolume *vm, int, int device) : ctx(nullptr), m_vol(vm), tlut(nullptr), failed(0) {
+HipVolumeRenderer::HipVolumeRenderer(MetaVolume *vm, int, int device) : ctx(nullptr), m_vol(vm), tlut(nullptr), failed(0), m_bb(0), m_bbb(0) {
   int err = 0;
   ctx = smk_create(device, &err);
   if (!ctx) {
@@ -115,6 +115,29 @@ void HipVolumeRenderer::renderVolume(float sampleRate, double mv[16]) {
   }
 }
 
+void HipVolumeRenderer::renderVolume(float sampleRate, double mv[16], float xext[2], float yext[2], float zext[2]) {
+  if (!ok()) return;
+  // (render3DVolumeEXTSV clamps the extents to the volume and returns when nothing is left, VolumeRenderer.cpp:452-463)
+  const float lo[3] = {xext[0], yext[0], zext[0]}, hi[3] = {xext[1], yext[1], zext[1]};
+  if (smk_set_region(ctx, 1, lo, hi)) {
+    std::cerr << "ERROR: HipVolumeRenderer::renderVolume: " << smk_last_error(ctx) << std::endl;
+    failed = 1;
+    return;
+  }
+  renderVolume(sampleRate, mv);
+  smk_set_region(ctx, 0, nullptr, nullptr);
+}
+
+void HipVolumeRenderer::renderSlice(float quad[4][3], float alpha) {
+  if (!ok()) return;
+  const size_t npix = (size_t)gluvv.win.width * (size_t)gluvv.win.height;
+  if (fb.size() != npix * 4) fb.assign(npix * 4, 0.0f);  // (no frame yet: the slice goes onto a cleared one)
+  if (smk_render_slice(ctx, quad, alpha, fb.data())) {
+    std::cerr << "ERROR: HipVolumeRenderer::renderSlice: " << smk_last_error(ctx) << std::endl;
+    failed = 1;
+  }
+}
+
 // -------------------------------------------------------------------------------------------
 
 void HipVolumeRenderable::init() {
@@ -151,6 +174,8 @@ void HipVolumeRenderable::createNoiseTex(int sx, int sy, int sz) {
         for (int e = 0; e < 4; ++e)
           noise[(size_t)i * sx * sy * 4 + (size_t)j * sx * 4 + k * 4 + e] = (unsigned char)(((rand() / (float)RAND_MAX * .5) + .5 + 1.0 / 512) * 255);
 }
+
+void HipVolumeRenderable::modelview(double mv[16]) { build_modelview(mv); }
 
 void HipVolumeRenderable::draw() {
   if (!go || !volren) return;

@@ -1,7 +1,8 @@
 // HipVolumeRenderer.h -- host-side mirror of the reference renderer interface over the C ABI.
 //
 //   HipVolumeRenderer   same public surface as VolumeRenderer (VolumeRenderer.h:86-118):
-//                       createVolume x2, createTLUT, getColorMap, renderVolume(sampleRate, mv)
+//                       createVolume x2, createTLUT, getColorMap, renderVolume(sampleRate, mv[, x/y/zext]),
+//                       renderSlice(quad, alpha), useBBox / useBBoxBrackets
 //   HipVolumeRenderable a gluvvPrimitive whose init()/draw() do what VolumeRenderable (scalar,
 //                       1-D TLUT; VolumeRenderable.cpp:36-82) and NV20VolRen3D/R8kVolRen3D (VGH,
 //                       deptex/deptex2, Phong; NV20VolRen3D.cpp:44-185) do, minus OpenGL: the
@@ -44,6 +45,16 @@ class HipVolumeRenderer {
   HipTLUT *colorMap() { return tlut; }  // the same object with the GL-free opacity correction
   // one frame; mv = column-major modelview as glGetDoublev returns it (VolumeRenderable.cpp:47-48)
   void renderVolume(float sampleRate, double mv[16]);
+  // a smaller axis-aligned box of the volume (VolumeRenderer.h:103-108): extents in volume space
+  void renderVolume(float sampleRate, double mv[16], float xext[2], float yext[2], float zext[2]);
+  // one textured quad blended into the frame of the last renderVolume (VolumeRenderer.h:114; camera of that call)
+  void renderSlice(float quad[4][3], float alpha);
+  // bounding box and brackets (VolumeRenderer.h:122-123): GL line drawing in the reference; kept so that callers
+  // compile, and readable by a host that draws its own overlay
+  void useBBox(int on_off) { m_bb = on_off; }
+  void useBBoxBrackets(int on_off) { m_bbb = on_off; }
+  int bbox() const { return m_bb; }
+  int bboxBrackets() const { return m_bbb; }
   // the frame of the last renderVolume: [height][width][4] premultiplied float RGBA
   const float *framebuffer() const { return fb.data(); }
   int ok() const { return ctx != nullptr && !failed; }
@@ -59,6 +70,8 @@ class HipVolumeRenderer {
   HipTLUT *tlut;
   std::vector<float> fb;
   int failed;
+  int m_bb;
+  int m_bbb;
 };
 
 class HipVolumeRenderable final : public gluvvPrimitive {
@@ -69,6 +82,9 @@ class HipVolumeRenderable final : public gluvvPrimitive {
   void draw();
   const float *framebuffer() const { return volren ? volren->framebuffer() : nullptr; }
   int running() const { return go; }
+  HipVolumeRenderer *renderer() { return volren; }  // the inner interface (VolumeRenderable keeps it private; a host that
+                                                    // draws sub-boxes or slice quads needs it)
+  static void modelview(double mv[16]);             // what draw() hands renderVolume: LookAt * T(trans) * R(xform) * T(-fSize/2)
 
  private:
   void createNoiseTex(int sx, int sy, int sz);  // R8kVolRen3D_cpy::createNoiseTex (:2392-2436)

@@ -58,6 +58,8 @@ int main(int argc, char **argv) {
   const char *out = argv[a++];
   std::vector<unsigned char> dep2;
   int dmode_arg = -1;
+  bool have_sub = false, have_slice = false;  // the inner interface: renderVolume(.., xext, yext, zext), renderSlice(quad, alpha)
+  float sub[6] = {0, 0, 0, 0, 0, 0}, quad[4][3] = {{0}}, slice_alpha = 1.f;
   for (; a < argc; ++a) {  // optional state a GUI session would have set
     const std::string kv = argv[a];
     const size_t eq = kv.find('=');
@@ -72,6 +74,12 @@ int main(int argc, char **argv) {
       gluvv.light.shadow = 1;
       sscanf(v.c_str(), "%d,%f", &gluvv.light.buffsz[0], &gluvv.light.gShadowQual);
       gluvv.light.buffsz[1] = gluvv.light.buffsz[0];
+    }
+    else if (k == "subbox") { have_sub = true; sscanf(v.c_str(), "%f,%f,%f,%f,%f,%f", &sub[0], &sub[1], &sub[2], &sub[3], &sub[4], &sub[5]); }
+    else if (k == "slice") {
+      have_slice = true;
+      sscanf(v.c_str(), "%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f,%f", &slice_alpha, &quad[0][0], &quad[0][1], &quad[0][2], &quad[1][0], &quad[1][1], &quad[1][2],
+             &quad[2][0], &quad[2][1], &quad[2][2], &quad[3][0], &quad[3][1], &quad[3][2]);
     }
     else if (k == "pert") {
       gluvv.pert.on = 1;
@@ -115,6 +123,20 @@ int main(int argc, char **argv) {
   }
   for (gluvvPrimitive *p = renderables.getNext(); p; p = p->getNext()) p->draw();   // display()
   if (!r->running()) return 4;
+  if (have_sub || have_slice) {
+    // VolumeRenderer's inner interface, used the way a caller of the reference class would (VolumeRenderer.h:86-123)
+    HipVolumeRenderer *vr = r->renderer();
+    vr->useBBox(1);
+    vr->useBBoxBrackets(0);
+    double mvm[16];
+    HipVolumeRenderable::modelview(mvm);
+    if (have_sub) {
+      float xe[2] = {sub[0], sub[1]}, ye[2] = {sub[2], sub[3]}, ze[2] = {sub[4], sub[5]};
+      vr->renderVolume(gluvv.volren.sampleRate, mvm, xe, ye, ze);
+    }
+    if (have_slice) vr->renderSlice(quad, slice_alpha);
+    if (!vr->ok()) return 5;
+  }
   FILE *f = fopen(out, "wb");
   fwrite(r->framebuffer(), 4, (size_t)gluvv.win.width * gluvv.win.height * 4, f);
   fclose(f);

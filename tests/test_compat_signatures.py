@@ -189,3 +189,26 @@ def test_adapter_compiles_against_the_reference_headers(tmp_path):
     syms = subprocess.run(["nm", "-C", "--undefined-only", str(obj)], capture_output=True, text=True).stdout
     assert "TLUT::TLUT(int)" in syms and "gluvvPrimitive::" in syms
     assert "TLUT::scaleAlpha" not in syms and "loadTransferTableRGBA" not in syms.replace("HipVolumeRenderer::loadTransferTableRGBA", "")
+
+
+def test_hip_volume_renderer_has_the_inner_interface_of_volume_renderer():
+    """what VolumeRenderable needs from VolumeRenderer (VolumeRenderer.h:86-123).  Every public method of the
+    reference class that is not GL/NRRD plumbing must exist in HipVolumeRenderer with the same return type and parameter
+    types (GLdouble is double, GL/gl.h)."""
+    rc, _ = parse_header(os.path.join(REF, "VolumeRenderer.h"))
+    hc, _ = parse_header(os.path.join(HOST, "HipVolumeRenderer.h"))
+    ref, mine = rc["VolumeRenderer"], hc["HipVolumeRenderer"]
+    gl = lambda k: k.replace("GLdouble", "double")   # noqa: E731
+    ref = {gl(k): v for k, v in ref.items()}
+    wanted = ["createVolume(int,Volume*)", "createVolume(int,Volume*,int)", "createTLUT()", "getColorMap()",
+              "renderVolume(float,double[16])", "renderVolume(float,double[16],float[2],float[2],float[2])",
+              "renderSlice(float[4][3],float)", "useBBox(int)", "useBBoxBrackets(int)"]
+    problems = []
+    for key in wanted:
+        if key not in ref:
+            problems.append("the reference's VolumeRenderer has no %s (the test's list is stale)" % key)
+        elif key not in mine:
+            problems.append("HipVolumeRenderer lacks %s" % key)
+        elif mine[key] != ref[key]:
+            problems.append("%s returns '%s' here, '%s' in the reference" % (key, mine[key], ref[key]))
+    assert not problems, "\n".join(problems)

@@ -116,11 +116,13 @@ def test_full_size_two_shards_composite_to_whole(gpu_renderer_factory):
             r.close()
 
 
-def test_full_size_cfg5_multi_field_perturbed(gpu_renderer_factory, O):
+@pytest.mark.parametrize("weights,halo", [((.2, .1, 0, 0), 80), ((.02, .01, 0, 0), 16)])
+def test_full_size_cfg5_multi_field_perturbed(gpu_renderer_factory, O, weights, halo):
     """BASELINE config 5 at its full size: two 512^3 fields merged on the GPU (mergeMV + addG),
     dense 3-D transfer function, testPert's noise-perturbed fetch, 1024^2 x 1024 planes (gather
-    kernel).  The CPU checker agrees on 300 random rays of the frame, and the frame rendered as two
-    brick shards (halo wide enough for the perturbation) composites back to it."""
+    kernel) -- at the weights SURVEY 8(d) states, (.2, .1): displacements of up to 77 voxels, and at a
+    tenth of them.  The CPU checker agrees on 300 random rays of the frame, and the frame rendered as two
+    brick shards (halo wide enough for the perturbation: 0.5 * 0.3 * 512 + the texel pair) composites back to it."""
     import torch
     import _scenes as S
     n, size, planes = 512, 1024, 1024
@@ -151,7 +153,7 @@ def test_full_size_cfg5_multi_field_perturbed(gpu_renderer_factory, O):
             rr.set_camera(mv, b.FRUSTUM, (1.0, 20.0), size, size)
             rr.set_sampling(0.0, planes, 1.0, 1)
             rr.set_shading("r8k", b.LIGHT, b.EYE, b.AT, [float(v) for v in xform.T.reshape(-1)], b.INTENS)
-            rr.set_perturb(noise, (.02, .01, 0, 0), (.2, 2.1, 4.5, 8.7))
+            rr.set_perturb(noise, weights, (.2, 2.1, 4.5, 8.7))
             rr.set_option("kernel", 0)
 
         setup(r)
@@ -164,7 +166,7 @@ def test_full_size_cfg5_multi_field_perturbed(gpu_renderer_factory, O):
         for _ in range(3):
             r.render_device(whole.data_ptr(), None, None)
         torch.cuda.synchronize()
-        print("cfg5 at full size, one GPU, gather kernel: %.2f ms per 1024 x 1024 x 1024-plane frame" % ((time.perf_counter() - t0) / 3 * 1e3))
+        print("cfg5 at full size, weights %s, one GPU, gather kernel: %.2f ms per 1024 x 1024 x 1024-plane frame" % (weights[:2], (time.perf_counter() - t0) / 3 * 1e3))
         w = whole.cpu().numpy().reshape(size, size, 4)
         assert w[..., 3].max() > 0.5
         sc = O.Scene(merged.cpu().numpy(), grad=nrm.cpu().numpy())
@@ -175,7 +177,7 @@ def test_full_size_cfg5_multi_field_perturbed(gpu_renderer_factory, O):
         sc.mv_override = mv
         sc.shade_mode, sc.use_spec = 1, 1
         sc.frustum = b.FRUSTUM
-        sc.noise, sc.pert_w, sc.pert_s = noise, (.02, .01, 0, 0), (.2, 2.1, 4.5, 8.7)
+        sc.noise, sc.pert_w, sc.pert_s = noise, weights, (.2, 2.1, 4.5, 8.7)
         rng = np.random.default_rng(8)
         pix = rng.integers(0, size, size=(300, 2)).astype(np.int32)
         ref = sc.render_pixels(pix)
@@ -186,7 +188,7 @@ def test_full_size_cfg5_multi_field_perturbed(gpu_renderer_factory, O):
         for rank in (0, 1):
             rr = gpu_renderer_factory()
             rs.append(rr)
-            rr.set_option("halo", 16)         # .03 of 512 voxels of displacement + the texel pair
+            rr.set_option("halo", halo)       # half the summed weights of 512 voxels of displacement + the texel pair
             rr.set_shard(rank, 2)
             setup(rr)
             rr.render_device(layers[rank].data_ptr(), None, None)
