@@ -51,7 +51,7 @@ def pmc_insts(workload):
     """Per-launch instruction counters of the ray-march kernel from the committed SQ passes
     (profiles/rNN_pmc_sq_<cfg3|ns>.txt, written by tools/profile_round.sh + tools/pmc_summary.py)."""
     d = os.path.join(ROOT, "profiles")
-    suffix = "_pmc_sq_%s.txt" % ("cfg3" if workload == "cfg3" else "ns")
+    suffix = "_pmc_sq_%s.txt" % {"cfg3": "cfg3", "north_star": "ns", "cfg3_dense": "cfg3_dense", "north_star_dense": "ns_dense"}.get(workload, "ns")
     paths = sorted(p for p in os.listdir(d) if p.endswith(suffix)) if os.path.isdir(d) else []
     if not paths:
         return None
@@ -248,6 +248,52 @@ def roofline(r, kms, alg_bytes, size, note=None, traffic=None):
     return out
 
 
+def sample_counts(r, frame, size, planes):
+    """the nominal sample count next to the samples that lie inside the volume and the samples the kernel
+    really interpolates (with empty-space skipping on, samples of layers in which nothing can be visible are never taken;
+    a ray stops at alpha == 1).  Counted outside the timed region: the in-volume count by the renderers' membership test
+    alone (smk_count_samples), the taken count by the slice-ring kernel's diagnostic instance (option lockstep bit 16)."""
+    out = {"nominal": int(size) * int(size) * int(planes), "in_volume": r.count_samples(), "taken": None}
+    kernel = r.last_frame_info()[0]
+    if kernel == 2:
+        r.set_option("lockstep", 1 | 16)
+        r.render_device(frame.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        if r.last_frame_info()[0] == 2:
+            out["taken"] = int(r.stat("slab_inside_lanes"))
+        r.set_option("lockstep", 1)
+        r.render_device(frame.data_ptr(), None, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    return out
+
+
+def workgroup_load(r):
+    """longest workgroup against the mean load of a workgroup slot (256 CUs x 2 small or x 1 big workgroups), ms"""
+    if r.last_frame_info()[0] != 2:
+        return None
+    mx, sm = float(r.stat("slab_tile_ms_max")), float(r.stat("slab_tile_ms_sum"))
+    return {"longest_workgroup_ms": mx, "sum_ms": sm, "sum_ms_per_cu": sm / 256.0, "tiles_cut_in_depth": int(r.stat("slab_split_tiles")),
+            "workgroups": int(r.stat("slab_workgroups"))}
+
+
+def dense_leg(r, work, frame, size, planes, steps, workload_key):
+    """The worst case for empty-space skipping at full size: the reference's default (value, gradient) ramp
+    (NV20VolRen3D.cpp:1479-1486) -- every sample is visible, classified, shaded and blended; the flags skip nothing."""
+    K = max(3, min(steps, 8))
+    g = os.path.join(ROOT, "tests", "golden")
+    r.set_tf2d(np.load(os.path.join(g, "tf_cfg2_deptex.npy")), None)
+    with torch.cuda.stream(work):
+        run_frames(r, 60, frame, 1, None)
+        t, kms, kn = timed(r, K, 2, frame, 1, None)
+    kernel, _, alg = r.last_frame_info()
+    out = {"workload": "the same volume, camera and shading under the reference's default ramp table (dense: every sample visible)",
+           "ms_per_frame": t / K * 1e3, "Msamples_per_s": float(size) * size * planes / (t / K) / 1e6,
+           "kernel": {1: "gather", 2: "slab-staged", 4: "column-stream"}.get(kernel, str(kernel)),
+           "roofline": roofline(r, kms, alg, size), "roofline_valu": roofline_valu(kms, workload_key),
+           "samples": sample_counts(r, frame, size, planes), "workgroups": workgroup_load(r)}
+    return out
+
+
 def no_flags_leg(r, work, frame, size, planes, steps):
     """The same frame with empty-space skipping off (option "bricks" 0): every slice of every tile is streamed and every
     sample interpolated and classified -- the streaming kernel's own roofline.  The frames are bit-identical
@@ -269,6 +315,38 @@ def no_flags_leg(r, work, frame, size, planes, steps):
     return {"ms_per_frame": t / K * 1e3, "Msamples_per_s": float(size) * size * planes / (t / K) / 1e6,
             "kernel": {1: "gather", 2: "slab-staged"}.get(kernel, str(kernel)), "roofline": rl,
             "frame_bit_identical_to_the_one_with_flags": same}
+
+
+def column_stream_leg(r, work, frame, size, planes, steps):
+    """The same frame on the column-stream kernel (option kernel = 3, smk_cols.hip) with empty-space skipping off: the
+    volume re-laid out in columns with their halo, each streamed sequentially once.  Its byte count is what its loaders
+    move (the layout's bytes: every voxel and its column's halo once), not an estimate."""
+    K = max(3, min(steps, 8))
+    keep = frame.clone()
+    r.set_option("bricks", 0)
+    r.set_option("kernel", 3)
+    try:
+        with torch.cuda.stream(work):
+            run_frames(r, 3, frame, 1, None)
+            t, kms, kn = timed(r, K, 1, frame, 1, None, settle=False)
+        kernel, _, alg = r.last_frame_info()
+        cfg = int(r.stat("cols_config"))
+        sb = float(r.stat("cols_stream_bytes"))
+        out = {"ms_per_frame": t / K * 1e3, "kernel_ms": kms, "kernel": "column-stream" if kernel == 4 else str(kernel),
+               "column_cells": [cfg & 255, (cfg >> 8) & 255], "ring_slots": (cfg >> 16) & 255, "jobs": int(r.stat("cols_jobs")),
+               "streamed_bytes_per_launch": sb, "streamed_over_algorithmic": sb / alg if alg else None,
+               "streamed_GBps": sb / (kms * 1e-3) / 1e9 if kms > 0 else None,
+               "algorithmic_GBps": alg / (kms * 1e-3) / 1e9 if kms > 0 else None, "frac_of_8000": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS if kms > 0 else None,
+               "max_abs_diff_vs_the_slice_ring_frame": float((keep - frame).abs().max().item()),
+               "note": "same samples, blend re-associated per column job: <= 2e-5 (tests/test_gpu_cols.py); bound by vector-instruction issue, "
+                       "not by its stream (DESIGN.md 4e)"}
+    except Exception as e:  # noqa: BLE001  (reported, never silent)
+        out = {"error": str(e)[:300]}
+    r.set_option("kernel", 0)
+    r.set_option("bricks", 1)
+    with torch.cuda.stream(work):
+        run_frames(r, 40, frame, 1, None)
+    return out
 
 
 def libc_noise_tex(n=32):
@@ -314,7 +392,7 @@ def extra_legs(r, frame, work, steps):
         r.set_option("kernel", 0)
         kernel, _, alg = r.last_frame_info()
         out[name] = {"workload": describe, "ms_per_frame": t / K * 1e3, "Msamples_per_s": float(size) * size * planes / (t / K) / 1e6,
-                     "kernel": {1: "gather", 2: "slab-staged"}.get(kernel, str(kernel)),
+                     "kernel": {1: "gather", 2: "slab-staged", 4: "column-stream"}.get(kernel, str(kernel)),
                      "roofline": roofline(r, kms, alg, size)}
 
     # cfg2: 256^3 u8 VGH, the reference's default deptex ramp (NV20VolRen3D.cpp:1479-1486), 512^2 x 256, no shading
@@ -353,6 +431,9 @@ def extra_legs(r, frame, work, steps):
     run("opaque_tf_auto", 1024, 512, "the same frame in auto mode (whichever kernel measured faster); no byte count for the gather kernel")
     if out["opaque_tf_auto"]["kernel"] == "gather":
         out["opaque_tf_auto"]["roofline"] = None
+    # the worst case for empty-space skipping at the headline size: cfg 3 under the reference's default ramp
+    configure(r, "cfg3", n, 1024, 512)
+    out["cfg3_dense_ramp"] = dense_leg(r, work, frame[:1024 * 1024], 1024, 512, steps, "cfg3_dense")
     # cfg3 with the shadow check box on (half-angle slicing, light buffer 1024 x quality .5 = 512^2, light up-left of the eye)
     configure(r, "cfg3", n, 1024, 512)
     r.set_shading("r8k", (3.0, 4.0, -3.0), EYE, AT, xf, INTENS)
@@ -641,12 +722,27 @@ def main():
         out["roofline"]["kernel_frames_timed"] = kn
         if default_workload and world == 1:
             out["roofline_valu"] = roofline_valu(kms, "cfg3")
+        if world == 1:
+            out["samples"] = sample_counts(r, frame, size, planes)
+        out["workgroups"] = workgroup_load(r)
         if world == 1 and not a.no_extra and flags_on:
             out["without_brick_flags"] = no_flags_leg(r, work, frame, size, planes, a.steps)
     failures = int(r.stat("slab_failures"))
     if world > 1:
-        out["rccl_ranks"] = 0 if rehearse else world
+        # every rank's own figures on the one line: kernel time of its shard, longest workgroup against the mean slot load,
+        # what it waited for the merge; the ranks that really spoke RCCL
+        mine = {"rank": rank, "kernel_ms": kms, "kernel": {1: "gather", 2: "slab-staged", 4: "column-stream"}.get(kernel, str(kernel)),
+                "workgroups": workgroup_load(r), "exchange_object": bool(cstate is not None and hasattr(cstate[0], "x")),
+                "ms_per_step_this_rank": ms}
+        per = [None] * world
+        dist.all_gather_object(per, mine)
+        out["per_rank"] = per
+        # ranks whose layers cross the node through RCCL: all of them unless this is the one-GPU rehearsal (gloo through host
+        # memory); of those, the ranks whose merge runs behind the C ABI (smk_exchange_*) rather than through torch.distributed
+        out["rccl_ranks"] = 0 if rehearse else sum(1 for p_ in per if p_ is not None)
+        out["smk_exchange_ranks"] = 0 if rehearse else sum(1 for p_ in per if p_ and p_["exchange_object"])
         out["exchange"] = exchange_mode
+        out["exchange_ms_estimate"] = max(0.0, ms - max(p_["kernel_ms"] for p_ in per if p_))   # what a frame takes beyond the slowest rank's ray-march
         out["frames_repaired"] = int(cstate[0].repaired)
         ft = torch.tensor([failures, out["frames_repaired"]], dtype=torch.int64, device="cuda" if not rehearse else "cpu")
         dist.all_reduce(ft, op=dist.ReduceOp.SUM)
@@ -698,8 +794,11 @@ def main():
             "workload": "cfg4 single GPU: %d^3 f32 VGH + u8 normals, (v,g)x(h) TF, R8k Phong, %dx%dx%d" % (nn_, size, size, planes),
             "ms_per_frame": t2 / k2 * 1e3, "fps": k2 / t2, "Msamples_per_s": samples / (t2 / k2) / 1e6,
             "roofline": rl2, "kernel": {1: "gather", 2: "slab-staged"}.get(kernel2, str(kernel2))}
+        out["north_star"]["samples"] = sample_counts(r, frame, size, planes)
+        out["north_star"]["workgroups"] = workgroup_load(r)
         if not a.no_extra and flags_on:
             out["north_star"]["without_brick_flags"] = no_flags_leg(r, work, frame, size, planes, a.steps)
+            out["north_star"]["column_stream_kernel"] = column_stream_leg(r, work, frame, size, planes, a.steps)
         if not a.no_cpu:
             # parity of the north-star frame itself: the CPU checker on 200 random rays of it
             torch.cuda.synchronize()
@@ -708,8 +807,11 @@ def main():
             out["north_star"]["parity_max_abs_err"] = north_star_parity(v2h, g2h, tf_eff2, size, planes, xform, mv2, ns_frame)
         del v2h, g2h
         if not a.no_extra:
+            out["north_star"]["dense_ramp"] = dense_leg(r, work, frame, size, planes, a.steps, "north_star_dense")
             out["extra"] = extra_legs(r, frame, work, a.steps)
     bad = out["slab_failures"] != 0 or r.stat("slab_retries") != 0
+    # a run that was meant to exchange over RCCL and did not (on every rank) must not pass for a scaling point
+    rccl_short = world > 1 and not rehearse and rank == 0 and out.get("rccl_ranks") != world
     if not flags_on:
         out["data"] += "; SMK_BENCH_BRICKS=0: empty-space skipping off (a profiling run, not the product's default)"
     if rank == 0:
@@ -719,6 +821,9 @@ def main():
     r.close()
     if world > 1:
         dist.destroy_process_group()
+    if rccl_short:
+        print("bench.py: %s of %d ranks exchange through RCCL (smk_exchange_*): %s" % (out.get("rccl_ranks"), world, out.get("exchange")), file=sys.stderr)
+        sys.exit(4)
     if bad:   # a frame the slice-ring kernel flagged would make the timing meaningless: fail loudly
         print("bench.py: slice-ring kernel flagged %d frame(s)" % out["slab_failures"], file=sys.stderr)
         sys.exit(3)

@@ -306,6 +306,10 @@ int smk_get_brick_flags(smk_ctx *ctx, unsigned char *flags_out, int *nb_out, int
  *   diagnostics, see tools/kbench.py), "wave_w"/"blk_w" (gather tile shape), "inject_slab_status"
  *   (test hook: the next slice-ring frame reports this status word) */
 int smk_set_option(smk_ctx *ctx, const char *key, int value);
+/* samples of the current frame set-up that lie inside the volume (region and clip planes counted in): the renderers'
+ * membership test for every plane of every ray, nothing fetched.  SURVEY 8(d)'s "in-volume sample count", to be read
+ * beside the nominal width x height x planes.  Synchronises. */
+int smk_count_samples(smk_ctx *ctx, double *in_volume);
 /* last frame: which kernel ran (1 gather, 2 slice-ring, 3 the per-slice shadow passes), its HIP-event time in ms,
  * algorithmic bytes */
 int smk_last_frame_info(smk_ctx *ctx, int *kernel, float *ms, double *alg_bytes);
@@ -314,7 +318,8 @@ int smk_last_frame_info(smk_ctx *ctx, int *kernel, float *ms, double *alg_bytes)
 int smk_timing_reset(smk_ctx *ctx);
 int smk_timing_read(smk_ctx *ctx, float *avg_ms, int *nframes);
 /* named counters of the last frame (developer statistics, no reference counterpart):
- * "slab_iters", "slab_active_lanes", "slab_inside_lanes", "slab_hit_lanes" (collected when option
+ * "slab_iters", "slab_active_lanes", "slab_inside_lanes" (lanes that interpolate a sample: not skipped as part of an
+ * empty layer), "slab_hit_lanes" (collected when option
  * lockstep has bit 16 set), "slab_status" (these synchronise the device); "slab_failures",
  * "slab_retries" (host-side counters, no synchronisation). */
 int smk_get_stat(smk_ctx *ctx, const char *name, double *value);

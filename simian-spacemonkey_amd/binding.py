@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "smk_exchange_unique_id", "smk_exchange_create", "smk_exchange_connect_local", "smk_exchange_destroy",
     "smk_exchange_last_error", "smk_exchange_partial", "smk_exchange_acquire", "smk_exchange_rendered", "smk_exchange_frame",
     "smk_exchange_frame_local", "smk_exchange_wait", "smk_exchange_set_order",
-    "smk_set_region", "smk_render_slice", "smk_render_slice_device",
+    "smk_set_region", "smk_render_slice", "smk_render_slice_device", "smk_count_samples",
 ]
 
 # gluvvDataMode order (gluvv.h:221-235)
@@ -176,6 +176,7 @@ def load_library():
     L.smk_exchange_wait.argtypes = [C.c_void_p, C.c_void_p]
     L.smk_timing_reset.argtypes = [C.c_void_p]
     L.smk_timing_read.argtypes = [C.c_void_p, P(C.c_float), P(C.c_int)]
+    L.smk_count_samples.argtypes = [C.c_void_p, P(C.c_double)]
     _LIB = L
     return L
 
@@ -407,6 +408,12 @@ class Renderer:
         rc = RayCoef()
         self._ck(self.L.smk_get_raycoef(self.ctx, C.byref(rc)))
         return rc
+
+    def count_samples(self):
+        """samples of the current frame set-up that lie inside the volume (smk_count_samples)"""
+        v = C.c_double(0)
+        self._ck(self.L.smk_count_samples(self.ctx, C.byref(v)))
+        return int(v.value)
 
     def last_frame_info(self):
         k, ms, b = C.c_int(0), C.c_float(0), C.c_double(0)

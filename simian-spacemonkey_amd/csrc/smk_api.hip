@@ -1306,6 +1306,23 @@ extern "C" int smk_get_trace(smk_ctx *c, unsigned *out, int cap_records, int *nr
   return 0;
 }
 
+extern "C" int smk_count_samples(smk_ctx *c, double *in_volume) {
+  if (!c || !in_volume) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  RenderParams P;
+  if (build_params(c, P, c->stream)) return 1;
+  unsigned long long *d = nullptr, h = 0;
+  HIPCHK(c, hipMalloc((void **)&d, 8));
+  hipError_t e = hipMemsetAsync(d, 0, 8, c->stream);
+  if (e == hipSuccess) e = smk_launch_count_inside(P, d, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+  HIPCHK(c, e);
+  *in_volume = (double)h;
+  return 0;
+}
+
 extern "C" int smk_last_frame_info(smk_ctx *c, int *kernel, float *ms, double *alg_bytes) {
   if (!c) return 1;
   if (kernel) *kernel = c->last_kernel;

@@ -226,6 +226,39 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
   if (P.depth) P.depth[o] = first;
 }
 
+// How many samples of the frame lie inside the volume (region, clip planes): the membership predicate of the kernel
+// above evaluated for every plane of every ray, nothing fetched.  SURVEY 8(d) asks for this count beside the nominal
+// W * H * planes (most rays cross the volume, not every plane of them lands inside).
+__global__ __launch_bounds__(256) void smk_k_count_inside(const RenderParams P, unsigned long long *count) {
+  const int i = blockIdx.x * 16 + (threadIdx.x & 15), j = blockIdx.y * 16 + (threadIdx.x >> 4);
+  unsigned n = 0;
+  if (i < P.W && j < P.H) {
+    const smk_raycoef &rc = P.rc;
+    const float px = __fmaf_rn((float)i + 0.5f, rc.pxs, rc.pxl);
+    const float py = __fmaf_rn((float)j + 0.5f, rc.pys, rc.pyl);
+    float A[3], B[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      A[a] = __fmaf_rn(px, rc.Ax[a], __fmaf_rn(py, rc.Ay[a], rc.Ac[a]));
+      B[a] = __fmaf_rn(px, rc.Bx[a], __fmaf_rn(py, rc.By[a], rc.Bc[a]));
+    }
+    for (int m = 0; m < rc.nplanes; ++m) {
+      const float p0 = __fmaf_rn((float)m, B[0], A[0]), p1 = __fmaf_rn((float)m, B[1], A[1]), p2 = __fmaf_rn((float)m, B[2], A[2]);
+      bool in = (p0 >= P.lo[0] && (p0 < P.hi[0] || (P.top[0] && p0 <= P.hi[0]))) && (p1 >= P.lo[1] && (p1 < P.hi[1] || (P.top[1] && p1 <= P.hi[1]))) &&
+                (p2 >= P.lo[2] && (p2 < P.hi[2] || (P.top[2] && p2 <= P.hi[2])));
+      if (in && P.cplane_on) in = __fmaf_rn(p0, P.cplane[0], __fmaf_rn(p1, P.cplane[1], __fmaf_rn(p2, P.cplane[2], P.cplane[3]))) >= 0.0f;
+      n += in ? 1u : 0u;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(count, (unsigned long long)n);
+}
+
+hipError_t smk_launch_count_inside(const RenderParams &P, unsigned long long *d_count, hipStream_t s) {
+  hipLaunchKernelGGL(smk_k_count_inside, dim3((P.W + 15) / 16, (P.H + 15) / 16), dim3(256), 0, s, P, d_count);
+  return hipGetLastError();
+}
+
 template <int DT, int TF, int SH>
 static hipError_t launch(const RenderParams &P, hipStream_t s) {
   dim3 grid(8 * P.tiles_per_xcd), block(256);

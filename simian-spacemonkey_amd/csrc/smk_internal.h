@@ -301,6 +301,7 @@ hipError_t smk_bricks_flags(const float4 *mm, const int nb[3], const uint32_t *o
 // launchers (one translation unit per kernel family)
 hipError_t smk_launch_gather(const RenderParams &P, int dtype, int tf_mode, int shade_kind,
                              hipStream_t s);
+hipError_t smk_launch_count_inside(const RenderParams &P, unsigned long long *d_count, hipStream_t s);
 // one launch per slice (smk_shadow.hip); L0 cleared by the caller
 hipError_t smk_launch_shadow(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, int shade_kind,
                              float4 *L0, float4 *L1, hipStream_t s);

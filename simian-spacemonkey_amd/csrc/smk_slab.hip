@@ -1389,7 +1389,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
         if (count) {
           n_it += 1.f;
           n_act += (float)__popcll(__ballot(act));
-          n_in += (float)__popcll(__ballot(act));
+          n_in += (float)__popcll(__ballot(work));  // lanes that interpolate a sample (an empty layer's are skipped before that)
           n_hit += (float)__popcll(__ballot(d_hit));
           n_anyhit += __any(d_hit) ? 1.f : 0.f;
           n_work += __any(work) ? 1.f : 0.f;

@@ -47,6 +47,8 @@ def main():
         t = np.zeros((256, 256, 4), np.uint8)
         if a.tf == "opaque":
             t[:] = (200, 150, 100, 255)
+        if a.tf == "ramp":    # the reference's default (value, gradient) ramp (NV20VolRen3D.cpp:1479-1486): dense
+            t = np.load(os.path.join(ROOT, "tests", "golden", "tf_cfg2_deptex.npy"))
         r.set_tf2d(t, None)
     if a.pose.startswith("close"):
         # a close-up: strong perspective, rays far from the principal axis at the frame's edges

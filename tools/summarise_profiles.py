@@ -26,11 +26,35 @@ def pmc(d, name):
     return out
 
 
+def settled(kt, tag, prof, last=20):
+    """rocprofv3 --stats averages ALL launches of a kernel: the untimed settle frames of the benchmark run on a schedule
+    that is still adapting (the first launches on the geometric estimate), so the average sits above what bench.py times.
+    From the per-launch kernel trace: the launches in issue order, their median and minimum, and the mean of the LAST
+    `last` of them -- the timed steps (bench.py --steps 20: the default command's, or fewer when it timed fewer)."""
+    rows = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(kt, "**", "*_kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            if "smk_k_slab<" in k or "smk_k_gather<" in k or "smk_k_cols<" in k:
+                rows[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    out = {}
+    for k, v in rows.items():
+        v.sort()
+        d = [x[1] * 1e-6 for x in v]
+        tail = d[-min(last, len(d)):]
+        sd = sorted(d)
+        out[k] = {"launches": len(d), "mean_all_ms": sum(d) / len(d), "median_ms": sd[len(sd) // 2], "min_ms": sd[0],
+                  "mean_of_last_%d_ms" % len(tail): sum(tail) / len(tail), "first_8_ms": [round(x, 4) for x in d[:8]]}
+    json.dump(out, open(os.path.join(prof, tag + "_kernel_settled.json"), "w"), indent=1)
+    return out
+
+
 def main():
     tag, kt, fd, wd = sys.argv[1:5]
     prof = os.path.join(ROOT, "profiles")
     for f in glob.glob(os.path.join(kt, "**", "*_kernel_stats.csv"), recursive=True):
         shutil.copy(f, os.path.join(prof, tag + "_kernel_stats.csv"))
+    print(json.dumps(settled(kt, tag, prof), indent=1))
     fetch, write = pmc(fd, "FETCH_SIZE"), pmc(wd, "WRITE_SIZE")
     traffic = {}
     with open(os.path.join(prof, tag + "_pmc.txt"), "w") as fo:
@@ -41,7 +65,7 @@ def main():
             f_, w_ = fetch.get(k, []), write.get(k, [])
             fo.write("%-70s n=%3d FETCH min %.6g max %.6g | WRITE min %.6g max %.6g\n" % (
                 k[:70], len(f_), min(f_ or [0]), max(f_ or [0]), min(w_ or [0]), max(w_ or [0])))
-            if "smk_k_slab" in k or "smk_k_gather" in k:
+            if "smk_k_slab<" in k or "smk_k_gather<" in k or "smk_k_cols<" in k:
                 traffic[k] = {"fetch_kib": f_, "write_kib": w_}
     # bench.py uses one kernel instance per workload (light config for 512^3, heavy for 1024^3)
     res = {}
@@ -54,9 +78,11 @@ def main():
     # the default bench.py run marches two volumes: the smaller traffic belongs to the headline
     # workload (512^3), the larger to the north-star one (1024^3)
     # (auto mode times the gather kernel once per configuration: those trial launches are not the workload)
-    order = sorted((k for k in res if "smk_k_slab" in k), key=lambda k: res[k]["hbm_bytes_per_launch"])
+    order = sorted((k for k in res if "smk_k_slab<" in k), key=lambda k: res[k]["hbm_bytes_per_launch"])
     if len(order) == 2:
+        extra = {k: v for k, v in res.items() if k not in order}
         res = {"cfg3": dict(res[order[0]], kernel=order[0]), "north_star": dict(res[order[1]], kernel=order[1])}
+        res.update(extra)
     json.dump(res, open(os.path.join(prof, tag + "_traffic.json"), "w"), indent=1)
     print(json.dumps(res, indent=1))
 
