@@ -10,6 +10,94 @@
 
 static std::string g_create_err;
 
+// ------------------------------------------------------------------------------- host thread pool
+// Planning a frame (the slice-ring launcher's scan of every tile's ray bundle) is double arithmetic on the host's thread:
+// a pool of a few workers shares it.  One pool per process; contexts are used from one thread at a time (smk.h), a mutex
+// keeps two contexts on different threads from interleaving jobs.
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+namespace {
+struct HostPool {
+  std::vector<std::thread> workers;
+  std::mutex m, use;
+  std::condition_variable cv, done_cv;
+  const std::function<void(int)> *job = nullptr;
+  int njobs = 0, next = 0, pending = 0;
+  unsigned long long gen = 0;
+  bool quit = false;
+  explicit HostPool(int n) {
+    for (int i = 0; i < n; ++i)
+      workers.emplace_back([this] {
+        unsigned long long seen = 0;
+        for (;;) {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait(lk, [&] { return quit || (gen != seen && next < njobs); });
+          if (quit) return;
+          while (next < njobs) {
+            const int k = next++;
+            lk.unlock();
+            (*job)(k);
+            lk.lock();
+            if (--pending == 0) done_cv.notify_all();
+          }
+          seen = gen;
+        }
+      });
+  }
+  ~HostPool() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      quit = true;
+    }
+    cv.notify_all();
+    for (std::thread &t : workers) t.join();
+  }
+};
+HostPool *host_pool() {
+  static HostPool *pool = [] {
+    const char *e = getenv("SMK_HOST_THREADS");
+    int n = e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    n = std::max(1, std::min(n, 32));
+    return new HostPool(n - 1);  // (the caller is the n-th; never destroyed: workers must not outlive a static's destructor order)
+  }();
+  return pool;
+}
+}  // namespace
+
+int smk_host_pool_size() { return (int)host_pool()->workers.size() + 1; }
+
+void smk_host_pool_run(int n, const std::function<void(int)> &f) {
+  HostPool *p = host_pool();
+  if (n <= 1 || p->workers.empty()) {
+    for (int k = 0; k < n; ++k) f(k);
+    return;
+  }
+  std::lock_guard<std::mutex> one(p->use);
+  {
+    std::lock_guard<std::mutex> lk(p->m);
+    p->job = &f;
+    p->njobs = n;
+    p->next = 1;        // job 0 is the caller's
+    p->pending = n - 1;
+    ++p->gen;
+  }
+  p->cv.notify_all();
+  f(0);
+  std::unique_lock<std::mutex> lk(p->m);
+  // (help with what is left rather than wait for a worker to wake up)
+  while (p->next < p->njobs) {
+    const int k = p->next++;
+    lk.unlock();
+    f(k);
+    lk.lock();
+    --p->pending;
+  }
+  p->done_cv.wait(lk, [&] { return p->pending == 0; });
+  p->job = nullptr;
+  p->njobs = 0;
+}
+
 #define HIPCHK(ctx, call)                                                              \
   do {                                                                                 \
     hipError_t e_ = (call);                                                            \
@@ -98,6 +186,8 @@ extern "C" void smk_destroy(smk_ctx *c) {
     if (T.used) (void)hipEventDestroy(T.used);
   }
   if (c->tf_raw_ev) (void)hipEventDestroy(c->tf_raw_ev);
+  if (c->tf_ready) (void)hipEventDestroy(c->tf_ready);
+  if (c->tf_stream) { (void)hipStreamSynchronize(c->tf_stream); (void)hipStreamDestroy(c->tf_stream); }
   free_brick_set(c->br3);
   smk_cols_free(&c->cols);
   void *ptrs[] = {c->d_tf_raw, c->d_tlut, c->d_tf_h, c->d_tf3d, c->d_tf3d_occ, c->d_noise, c->d_out, c->d_depth, c->d_light[0], c->d_light[1]};
@@ -921,10 +1011,30 @@ static void tf2d_alpha_map(const smk_ctx *c, float sr, unsigned char map[256]) {
   for (int a = 0; a < 256; ++a) map[a] = (unsigned char)(int)((1.0 - pow((1.0 - (a / 255.0)), alphaScale)) * 255);
 }
 
-static int refresh_tf2d(smk_ctx *c, const smk_raycoef &rc, hipStream_t s) {
+static int refresh_tf2d(smk_ctx *c, const smk_raycoef &rc, hipStream_t frame_stream) {
   if (c->tf_mode != 1) return 0;
   const float sr = tf2d_rate(c, rc);
-  if (!c->tf_dirty && sr == c->tf_rate_applied && c->d_tf_vg) return 0;
+  if (!c->tf_dirty && sr == c->tf_rate_applied && c->d_tf_vg) {
+    if (c->tf_ready_pending) HIPCHK(c, hipStreamWaitEvent(frame_stream, c->tf_ready, 0));  // (a no-op once the refresh has run)
+    return 0;
+  }
+  // The correction is a function of the alpha BYTE: when the new rate maps every byte where the old one did -- a camera
+  // that turns a little changes the view-depth extent in its fifth digit -- the effective table, its occupancy bitmap and
+  // the brick flags would all come out byte for byte the same: nothing to refresh (a moving camera paid ~0.15 ms of
+  // stream time per frame for these launches).
+  unsigned char newmap[256];
+  tf2d_alpha_map(c, sr, newmap);
+  if (!c->tf_dirty && c->d_tf_vg && c->tf_map_valid && !memcmp(newmap, c->tf_map_applied, 256)) {
+    c->tf_rate_applied = sr;
+    if (c->tf_ready_pending) HIPCHK(c, hipStreamWaitEvent(frame_stream, c->tf_ready, 0));
+    return 0;
+  }
+  // The refresh (alpha map copy, effective table + bitmap, summed-area table, brick flags: four small launches) runs on a
+  // stream of its own and the frame's stream waits for its end: when the camera moves every frame the host enqueues frame
+  // i + 1's refresh while frame i is still ray-marching, and the two overlap instead of queueing up behind one another.
+  if (!c->tf_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->tf_stream, hipStreamNonBlocking));
+  if (!c->tf_ready) HIPCHK(c, hipEventCreateWithFlags(&c->tf_ready, hipEventDisableTiming));
+  const hipStream_t s = c->tf_stream;
   const size_t n = (size_t)c->sv * c->sg;
   const int sv = c->sv, sg = c->sg, roww = (sv + 31) / 32;
   const size_t occ_words = (size_t)roww * sg, bytes = n * 4 + occ_words * 4 + 256;  // table | bitmap | alpha map
@@ -965,7 +1075,9 @@ static int refresh_tf2d(smk_ctx *c, const smk_raycoef &rc, hipStream_t s) {
     c->tf_raw_stale = false;
   }
   unsigned char *map = T.h + n * 4 + occ_words * 4;
-  tf2d_alpha_map(c, sr, map);
+  memcpy(map, newmap, 256);
+  memcpy(c->tf_map_applied, newmap, 256);
+  c->tf_map_valid = true;
   if (T.used_valid) HIPCHK(c, hipStreamWaitEvent(s, T.used, 0));  // the last frame that read this version is done
   HIPCHK(c, hipMemcpyAsync(T.d + n * 4 + occ_words * 4, map, 256, hipMemcpyHostToDevice, s));
   HIPCHK(c, hipEventRecord(T.copied, s));
@@ -990,6 +1102,9 @@ static int refresh_tf2d(smk_ctx *c, const smk_raycoef &rc, hipStream_t s) {
   c->tf_occ_roww = roww;
   c->tf_rate_applied = sr;
   c->tf_dirty = false;
+  HIPCHK(c, hipEventRecord(c->tf_ready, s));
+  HIPCHK(c, hipStreamWaitEvent(frame_stream, c->tf_ready, 0));
+  c->tf_ready_pending = true;
   return 0;
 }
 

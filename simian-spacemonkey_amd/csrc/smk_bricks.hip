@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void smk_k_brick_minmax(const void *vox, int D
     gmin = fminf(gmin, __shfl_xor(gmin, o));
     gmax = fmaxf(gmax, __shfl_xor(gmax, o));
   }
-  if (lane == 0) mm[brick] = __any(bad) ? make_float4(1.0f, 0.0f, 1.0f, 0.0f) : make_float4(vmin, vmax, gmin, gmax);
+  const bool any_bad = __any(bad);  // (all 64 lanes vote: not inside the one-lane store)
+  if (lane == 0) mm[brick] = any_bad ? make_float4(1.0f, 0.0f, 1.0f, 0.0f) : make_float4(vmin, vmax, gmin, gmax);
 }
 
 // sat[(t + 1) * (sv + 1) + (s + 1)] = number of set bits (t', s') with t' <= t, s' <= s; one workgroup, a thread per

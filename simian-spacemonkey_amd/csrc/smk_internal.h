@@ -115,7 +115,7 @@ struct SlabAux {
   std::vector<unsigned char> cuts, cuts_pending, cuts_good;  // [ntiles][10] {K, cut_0..cut_K}: current | of the copy in flight | of pticks_good
   int cuts_split = -1;
   long long cuts_sig = -1;
-  bool recut = true, cuts_engaged = false;
+  bool recut = true, cuts_engaged = false, merge_warm = false;
   unsigned *d_trace = nullptr;  // [trace_n][8] workgroup timeline of the last traced frame (option lockstep bit 32)
   int trace_cap = 0, trace_n = 0;
 };
@@ -211,6 +211,9 @@ struct smk_ctx {
   size_t tf_raw_cap = 0;
   bool tf_raw_stale = true, tf_raw_ev_valid = false;
   hipEvent_t tf_raw_ev = nullptr;     // the last kernel that read d_tf_raw
+  hipStream_t tf_stream = nullptr;    // the table refresh runs here, beside the previous frame's ray-march
+  hipEvent_t tf_ready = nullptr;      // ... and a frame's stream waits for this
+  bool tf_ready_pending = false;
   uint32_t *d_tf_vg = nullptr, *d_tf_h = nullptr, *d_tf3d = nullptr;
   uint32_t *d_tf3d_occ = nullptr;  // occupancy of the dense 3-D table folded over its third axis (smk_set_tf3d)
   int tf3d_occ_roww = 0;
@@ -229,6 +232,8 @@ struct smk_ctx {
   int sv = 0, sg = 0, s3v = 0, s3g = 0, s3h = 0;
   bool tf_dirty = true;
   float tf_rate_applied = -1.f;
+  unsigned char tf_map_applied[256] = {0};  // the alpha-byte map the current effective table was made with
+  bool tf_map_valid = false;
 
   // camera
   bool have_camera = false;
@@ -312,3 +317,8 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
 // the column-stream kernel (smk_cols.hip); same convention as smk_launch_slab
 hipError_t smk_launch_cols(RenderParams P, int dtype, int tf_mode, int shade_kind, int knobs, const void *vox_native, ColsAux *aux,
                            int *status_word, const char **why, hipStream_t s);
+
+// a few host threads for the per-frame planning (smk_api.hip): run(n, f) calls f(0) .. f(n - 1), f(0) on the caller
+#include <functional>
+int smk_host_pool_size();
+void smk_host_pool_run(int n, const std::function<void(int)> &f);

@@ -1910,50 +1910,70 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
       max_eu = scan.v[0]; max_ev = scan.v[1]; max_drift_u = scan.v[2]; max_drift_v = scan.v[3];
       work = scan.work;
     } else
-    for (int tyi = 0; tyi < P.nty; ++tyi)
-      for (int txi = 0; txi < P.ntx; ++txi) {
-        if (pass == 0 && !(((txi & 3) == 0 || txi == P.ntx - 1) && ((tyi & 3) == 0 || tyi == P.nty - 1))) continue;  // (sparse probe)
-        double cA[4][3], cB[4][3];
-        for (int c = 0; c < 4; ++c) {
-          int cx = std::min(txi * tw + ((c & 1) ? tw - 1 : 0), P.W - 1);
-          int cy = std::min(tyi * th + ((c & 2) ? th - 1 : 0), P.H - 1);
-          double *A = cA[c], *B = cB[c];
-          host_ray(P, cx, cy, A, B);
-          if (!(B[as] * Q.dir > 0) || fabs(B[as]) < 1e-12) { *why = "rays do not share a marching direction"; return hipErrorNotSupported; }
-          double du = fabs(B[Q.au] / B[as]), dv = fabs(B[Q.av] / B[as]);
-          // (3 voxels of drift per slice: close-ups with a wide frustum reach ~2.5 at the frame's edge and still
-          //  run 2-3x faster here than on the gather kernel; the window bound below grows with the drift)
-          if (du > 3.0 || dv > 3.0) { *why = "view too oblique for the principal axis"; return hipErrorNotSupported; }
-          max_drift_u = std::max(max_drift_u, du);
-          max_drift_v = std::max(max_drift_v, dv);
-        }
-        // the slices this tile can stream: S-extent of its ray bundle inside the region (exact for
-        // the continuous bundle, see slab_bundle_slice_range)
-        double smin_t, smax_t;
-        if (!slab_bundle_slice_range(P, (double)(txi * tw), (double)(tyi * th), (double)std::min(txi * tw + tw, P.W),
-                                     (double)std::min(tyi * th + th, P.H), as, &smin_t, &smax_t))
-          continue;  // the bundle misses the region: nothing to stream
-        work[(size_t)tyi * P.ntx + txi] = 16 + (int)(smax_t - smin_t);
-        // cross-section of the bundle where THIS tile streams: it is linear in s (perspective), so
-        // the two ends of the tile's own slice range bound it.  A sample at s reads slices floor(s)
-        // and floor(s)+1, and the window of slice j covers s in [j-1, j+1] (stretched by half a
-        // slice at the volume faces): 2.5 slices beyond the range.  (Bounding by the volume's S
-        // faces instead costs 25-30 % window area at a voxel per pixel: rays are not inside the
-        // volume where they are widest apart.)
-        const double pad = 2.5 + 1e-2;
-        const double se[2] = {std::max(-0.5, smin_t - pad), std::min((double)P.N[as] - 0.5, smax_t + pad)};
-        for (int f = 0; f < 2; ++f) {
-          double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
-          for (int c = 0; c < 4; ++c) {
-            double mm = (se[f] - cA[c][as]) / cB[c][as];
-            double u = cA[c][Q.au] + cB[c][Q.au] * mm, v = cA[c][Q.av] + cB[c][Q.av] * mm;
-            umin = std::min(umin, u); umax = std::max(umax, u);
-            vmin = std::min(vmin, v); vmax = std::max(vmax, v);
+    {
+      // The rows of tiles are scanned by a few host threads (a pool the context keeps): ~0.13 us of double arithmetic per
+      // tile is 0.27 ms for the 2048 tiles of a 1024^2 viewport on one thread -- as much as a shard's whole kernel when the
+      // camera moves every frame.  Each thread keeps its own maxima and its own refusal; rows write disjoint tiles.
+      struct Part { double eu = 0, ev = 0, du = 0, dv = 0; const char *why = nullptr; };
+      auto scan_rows = [&](int ty0, int ty1, Part &pt) {
+        for (int tyi = ty0; tyi < ty1; ++tyi)
+          for (int txi = 0; txi < P.ntx; ++txi) {
+            if (pass == 0 && !(((txi & 3) == 0 || txi == P.ntx - 1) && ((tyi & 3) == 0 || tyi == P.nty - 1))) continue;  // (sparse probe)
+            double cA[4][3], cB[4][3];
+            for (int c = 0; c < 4; ++c) {
+              int cx = std::min(txi * tw + ((c & 1) ? tw - 1 : 0), P.W - 1);
+              int cy = std::min(tyi * th + ((c & 2) ? th - 1 : 0), P.H - 1);
+              double *A = cA[c], *B = cB[c];
+              host_ray(P, cx, cy, A, B);
+              if (!(B[as] * Q.dir > 0) || fabs(B[as]) < 1e-12) { pt.why = "rays do not share a marching direction"; return; }
+              double du = fabs(B[Q.au] / B[as]), dv = fabs(B[Q.av] / B[as]);
+              // (3 voxels of drift per slice: close-ups with a wide frustum reach ~2.5 at the frame's edge and still
+              //  run 2-3x faster here than on the gather kernel; the window bound below grows with the drift)
+              if (du > 3.0 || dv > 3.0) { pt.why = "view too oblique for the principal axis"; return; }
+              pt.du = std::max(pt.du, du);
+              pt.dv = std::max(pt.dv, dv);
+            }
+            // the slices this tile can stream: S-extent of its ray bundle inside the region (exact for
+            // the continuous bundle, see slab_bundle_slice_range)
+            double smin_t, smax_t;
+            if (!slab_bundle_slice_range(P, (double)(txi * tw), (double)(tyi * th), (double)std::min(txi * tw + tw, P.W),
+                                         (double)std::min(tyi * th + th, P.H), as, &smin_t, &smax_t))
+              continue;  // the bundle misses the region: nothing to stream
+            work[(size_t)tyi * P.ntx + txi] = 16 + (int)(smax_t - smin_t);
+            // cross-section of the bundle where THIS tile streams: it is linear in s (perspective), so
+            // the two ends of the tile's own slice range bound it.  A sample at s reads slices floor(s)
+            // and floor(s)+1, and the window of slice j covers s in [j-1, j+1] (stretched by half a
+            // slice at the volume faces): 2.5 slices beyond the range.  (Bounding by the volume's S
+            // faces instead costs 25-30 % window area at a voxel per pixel: rays are not inside the
+            // volume where they are widest apart.)
+            const double pad = 2.5 + 1e-2;
+            const double se[2] = {std::max(-0.5, smin_t - pad), std::min((double)P.N[as] - 0.5, smax_t + pad)};
+            for (int f = 0; f < 2; ++f) {
+              double umin = 1e300, umax = -1e300, vmin = 1e300, vmax = -1e300;
+              for (int c = 0; c < 4; ++c) {
+                double mm = (se[f] - cA[c][as]) / cB[c][as];
+                double u = cA[c][Q.au] + cB[c][Q.au] * mm, v = cA[c][Q.av] + cB[c][Q.av] * mm;
+                umin = std::min(umin, u); umax = std::max(umax, u);
+                vmin = std::min(vmin, v); vmax = std::max(vmax, v);
+              }
+              pt.eu = std::max(pt.eu, umax - umin);
+              pt.ev = std::max(pt.ev, vmax - vmin);
+            }
           }
-          max_eu = std::max(max_eu, umax - umin);
-          max_ev = std::max(max_ev, vmax - vmin);
-        }
+      };
+      const int nthreads = (pass == 1 && P.nty >= 16 && P.ntx * P.nty >= 512) ? smk_host_pool_size() : 1;
+      std::vector<Part> parts((size_t)std::max(nthreads, 1));
+      if (nthreads <= 1) {
+        scan_rows(0, P.nty, parts[0]);
+      } else {
+        smk_host_pool_run(nthreads, [&](int k) { scan_rows((int)((long long)P.nty * k / nthreads), (int)((long long)P.nty * (k + 1) / nthreads), parts[(size_t)k]); });
       }
+      for (const Part &pt : parts) {
+        if (pt.why) { *why = pt.why; return hipErrorNotSupported; }
+        max_eu = std::max(max_eu, pt.eu); max_ev = std::max(max_ev, pt.ev);
+        max_drift_u = std::max(max_drift_u, pt.du); max_drift_v = std::max(max_drift_v, pt.dv);
+      }
+    }
     if (dbg_time) dbg_scan += dbg_now() - dbg_s0;
     if (!scan_hit && pass == 1) {  // (a scan that bailed out above returned, a probe is sparse: only complete ones are kept)
       scan.key.assign(reinterpret_cast<const unsigned char *>(&key), reinterpret_cast<const unsigned char *>(&key) + sizeof key);
@@ -2433,6 +2453,22 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
       if (e != hipSuccess) return e;
     }
     const int mtw = tw, mth = th;
+    // (the merge pass's first launch costs the host a few milliseconds of code loading, which lands between the frame's
+    //  events: paid here, in a context's first slice-ring frame -- not in the frame auto mode happens to be timing when
+    //  the first tiles are cut.  One block whose entry names tile 0 with ONE piece: it rewrites that tile's pixels with
+    //  themselves, before this frame's kernel writes them.)
+    if (!aux->merge_warm && nblocks_now >= 1) {
+      aux->merge_warm = true;
+      static const int2 one = make_int2(0 | (1 << 20), 0);
+      int2 *d_one = nullptr;
+      if (hipMalloc((void **)&d_one, sizeof one) == hipSuccess) {
+        if (hipMemcpyAsync(d_one, &one, sizeof one, hipMemcpyHostToDevice, s) == hipSuccess)
+          hipLaunchKernelGGL(smk_k_slab_merge, dim3(1), dim3(256), 0, s, (const int2 *)d_one, mtw, mth, P.ntx, P.W, P.H, (const float4 *)P.out, P.out, 0);
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(d_one);
+      }
+      (void)hipGetLastError();
+    }
     auto after_launch = [&](hipError_t e) -> hipError_t {
       if (e == hipSuccess && nsplit_now > 0) {
         hipLaunchKernelGGL(smk_k_slab_merge, dim3(nsplit_now), dim3(256), 0, s, (const int2 *)aux->d_order + nblocks_now, mtw, mth, P.ntx, P.W, P.H,

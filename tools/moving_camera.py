@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wall time per frame when the camera moves every frame (developer tool): the host plans each frame afresh, so
-this shows what planning costs beside the kernel.   python tools/moving_camera.py [volume] [frames]"""
+this shows what planning costs beside the kernel.   python tools/moving_camera.py [volume] [frames] [nranks]"""
 import os
 import sys
 import time
@@ -14,8 +14,11 @@ import bench  # noqa: E402
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     frames = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+    nranks = int(sys.argv[3]) if len(sys.argv) > 3 else 1     # > 1: the shard of rank nranks // 2 (a shorter kernel beside the same planning)
     pkg = bench.load_package()
     r = pkg.Renderer(0)
+    if nranks > 1:
+        r.set_shard(nranks // 2, nranks)
     vghf, nrm = bench.make_volume(r, n)
     r.upload_volume_device(vghf.data_ptr(), (n, n, n), 3, 1, nrm.data_ptr())
     del vghf, nrm
