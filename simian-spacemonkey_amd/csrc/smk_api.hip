@@ -190,7 +190,7 @@ extern "C" void smk_destroy(smk_ctx *c) {
   if (c->tf_stream) { (void)hipStreamSynchronize(c->tf_stream); (void)hipStreamDestroy(c->tf_stream); }
   free_brick_set(c->br3);
   smk_cols_free(&c->cols);
-  void *ptrs[] = {c->d_tf_raw, c->d_tlut, c->d_tf_h, c->d_tf3d, c->d_tf3d_occ, c->d_noise, c->d_out, c->d_depth, c->d_light[0], c->d_light[1]};
+  void *ptrs[] = {c->d_shadow_barrier, c->d_tf_raw, c->d_tlut, c->d_tf_h, c->d_tf3d, c->d_tf3d_occ, c->d_noise, c->d_out, c->d_depth, c->d_light[0], c->d_light[1]};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->slab.h_status) (void)hipHostFree(c->slab.h_status);
@@ -1161,6 +1161,7 @@ extern "C" int smk_set_option(smk_ctx *c, const char *key, int value) {
   else if (!strcmp(key, "slab_sched")) c->opt_slab_sched = value < 0 ? 0 : (value > 15 ? 15 : value);
   else if (!strcmp(key, "slab_ns")) c->opt_slab_ns = value < 0 ? 0 : (value > 63 ? 63 : value);
   else if (!strcmp(key, "tile")) c->opt_tile = value;
+  else if (!strcmp(key, "shadow_fused")) c->opt_lockstep = value ? (c->opt_lockstep | 256) : (c->opt_lockstep & ~256);  // (developer: all slices in one cooperative launch)
   else if (!strcmp(key, "slab_split")) c->slab.opt_split = value < 0 ? 0 : (value > 8 ? 8 : value);
   else if (!strcmp(key, "cols_shape")) c->opt_cols = (c->opt_cols & ~0xff) | (value & 0xff);
   else if (!strcmp(key, "cols_ns")) c->opt_cols = (c->opt_cols & ~0xff00) | ((value & 0xff) << 8);
@@ -1710,7 +1711,8 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
     HIPCHK(c, hipEventRecord(c->ev0, s));
     HIPCHK(c, hipMemsetAsync(c->d_light[0], 0, nl * 16, s));
     HIPCHK(c, hipMemsetAsync(d_rgba, 0, (size_t)c->W * c->H * 16, s));
-    hipError_t e = smk_launch_shadow(P, sc, c->dtype, c->tf_mode, sk, c->d_light[0], c->d_light[1], s);
+    if (!c->d_shadow_barrier) HIPCHK(c, hipMalloc((void **)&c->d_shadow_barrier, 16 * 9 * 4));  // (the common word + one per XCD, a cache line apart)
+    hipError_t e = smk_launch_shadow(P, sc, c->dtype, c->tf_mode, sk, c->d_light[0], c->d_light[1], c->d_shadow_barrier, s);
     if (e == hipErrorNotSupported) FAIL(c, "smk_render: no shadow kernel instance for this configuration");
     HIPCHK(c, e);
     HIPCHK(c, hipEventRecord(c->ev1, s));

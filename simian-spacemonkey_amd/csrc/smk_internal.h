@@ -258,6 +258,7 @@ struct smk_ctx {
   float4 *d_light[2] = {nullptr, nullptr};  // ping-pong light buffers, light_cap texels each
   size_t light_cap = 0;
   int light_final = 0, light_lb = 0;        // which one the last frame finished in, and its edge
+  unsigned *d_shadow_barrier = nullptr;     // the fused shadow launch's grid-barrier counter
 
   // perturbation
   uint32_t *d_noise = nullptr;
@@ -309,7 +310,7 @@ hipError_t smk_launch_gather(const RenderParams &P, int dtype, int tf_mode, int 
 hipError_t smk_launch_count_inside(const RenderParams &P, unsigned long long *d_count, hipStream_t s);
 // one launch per slice (smk_shadow.hip); L0 cleared by the caller
 hipError_t smk_launch_shadow(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, int shade_kind,
-                             float4 *L0, float4 *L1, hipStream_t s);
+                             float4 *L0, float4 *L1, unsigned *barrier /* one device word for the fused launch's grid barrier, or null */, hipStream_t s);
 // returns hipErrorNotSupported (and *why) when the frame must use the gather kernel
 hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kind, int opt_T, int opt_tile, int forced,
                            const void *vox_native, const void *vox_xmajor, SlabAux *aux, const char **why,

@@ -1,5 +1,5 @@
-// smk_shadow.hip -- half-angle-slicing shadows: one launch per slice, the eye pass and the light pass of
-// that slice side by side in one grid.
+// smk_shadow.hip -- half-angle-slicing shadows: the eye pass and the light pass of a slice side by side in one grid; all
+// slices in ONE cooperative launch with a grid barrier between them (smk_k_shadow_fused), or a launch per slice.
 //
 // Replaces R8kVolRen3D's shadow mode: the slice axis half-way between view and light direction
 // (R8kVolRen3D.cpp:296-326), volShadow's two draws per slice polygon (:1651-1868: the slice into the
@@ -13,7 +13,10 @@
 // an arbitrary position), so the frame is S small launches instead of one march; each sample is a
 // gather of 8 voxels from HBM/L2 like kernel G's.  Sample placement: the fma chains of smk_shadowcoef,
 // evaluated identically by the CPU checker.
+#include <stdlib.h>
 #include <string.h>
+
+#include <algorithm>
 
 #include "smk_device.h"
 
@@ -87,6 +90,7 @@ __device__ __forceinline__ bool shadow_maybe_visible(const RenderParams &P, floa
 }
 
 // bilinear lookup of the light buffer; texels outside it are 0 (the rest of the pbuffer stays cleared)
+template <bool COH = false>
 __device__ __forceinline__ void shadow_lookup(const float4 *L, int LB, float lx, float ly, float out[3]) {
   const float fx0 = floorf(lx - 0.5f), fy0 = floorf(ly - 0.5f);
   const float fx = (lx - 0.5f) - fx0, fy = (ly - 0.5f) - fy0;
@@ -97,7 +101,7 @@ __device__ __forceinline__ void shadow_lookup(const float4 *L, int LB, float lx,
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int x = x0 + (q & 1), y = y0 + (q >> 1);
-    t[q] = (x >= 0 && x < LB && y >= 0 && y < LB) ? L[(size_t)y * LB + x] : make_float4(0.f, 0.f, 0.f, 0.f);
+    t[q] = (x >= 0 && x < LB && y >= 0 && y < LB) ? shadow_ld4<COH>(L + (size_t)y * LB + x) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   out[0] = smk_lerp(smk_lerp(t[0].x, t[1].x, fx), smk_lerp(t[2].x, t[3].x, fx), fy);
   out[1] = smk_lerp(smk_lerp(t[0].y, t[1].y, fx), smk_lerp(t[2].y, t[3].y, fx), fy);
@@ -116,104 +120,216 @@ __device__ __forceinline__ bool shadow_brick_empty(const RenderParams &P, float 
   return !P.bricks[((size_t)(z0 >> SMK_BRICK_LOG2) * P.nbr[1] + (size_t)(y0 >> SMK_BRICK_LOG2)) * P.nbr[0] + (size_t)(x0 >> SMK_BRICK_LOG2)];
 }
 
+// one eye pixel of one slice: the sample on the pixel's ray in this slice, shaded under the light buffer as the previous
+// slices left it, blended into the frame
+// The fused kernel's slices meet at a barrier INSIDE one launch: what one workgroup writes of the frame and the light buffer
+// another, possibly on another XCD with its own L2, reads a slice later.  Those two buffers are therefore accessed with
+// device-scope (relaxed atomic) loads and stores, which go past the non-coherent cache levels -- the voxels and tables keep
+// their cache lines across the barrier (a device-wide cache write-back + invalidate per slice, which is what a plain
+// grid.sync() does, cost 130 us per slice: every slice re-read its voxels from memory).
+template <bool COH>
+__device__ __forceinline__ float4 shadow_ld4(const float4 *p) {
+  if (!COH) return *p;
+  const float *f = reinterpret_cast<const float *>(p);
+  float4 v;
+  v.x = __hip_atomic_load(f + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.y = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.z = __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.w = __hip_atomic_load(f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
+template <bool COH>
+__device__ __forceinline__ void shadow_st4(float4 *p, float4 v) {
+  if (!COH) { *p = v; return; }
+  float *f = reinterpret_cast<float *>(p);
+  __hip_atomic_store(f + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(f + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(f + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(f + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int DT, int TF, int SH, bool COH = false>
+__device__ __forceinline__ void shadow_eye_pixel(const RenderParams &P, const ShadowSlice &Q, int i, int j) {
+  const smk_shadowcoef &sc = Q.sc;
+  if (i >= P.W || j >= P.H) return;
+  const float px = __fmaf_rn((float)i + 0.5f, sc.pxs, sc.pxl), py = __fmaf_rn((float)j + 0.5f, sc.pys, sc.pyl);
+  const float nD = __fmaf_rn(px, sc.nDx, __fmaf_rn(py, sc.nDy, sc.nDc));
+  const float tau = __fdiv_rn(Q.num, nD);
+  if (!(tau > 0.0f) || isinf(tau)) return;
+  float p[3];
+  bool in = true;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float D = __fmaf_rn(px, sc.Dx[a], __fmaf_rn(py, sc.Dy[a], sc.Dc[a]));
+    p[a] = __fmaf_rn(tau, D, sc.Ec[a]);
+    in = in && p[a] >= -0.5f && p[a] <= (float)P.N[a] - 0.5f;
+  }
+  if (!in) return;
+  const size_t o = (size_t)j * P.W + i;
+  float4 C = shadow_ld4<COH>(P.out + o);
+  if (sc.front_to_back && C.w == 1.0f) return;  // exact: every later weight (1-A) is 0
+  if (shadow_brick_empty(P, p[0], p[1], p[2])) return;
+  float ch0, ch1, ch2, ch3, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+  shadow_fetch<DT, TF, SH != 0>(P, p[0], p[1], p[2], ch0, ch1, ch2, ch3, n0, n1, n2);
+  float4 col;
+  if (!shadow_maybe_visible<TF>(P, ch0, ch1)) return;
+  if (!smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col)) return;
+  // (the light-buffer texels depend on the position alone and could be requested before the voxels are classified,
+  //  shortening the chain of dependent gathers; measured: 12.28 vs 10.95 ms per 512-slice frame -- nine lookups in
+  //  ten are then made for transparent samples, and the slice is bound by gather throughput, not by latency)
+  const float lw = __fmaf_rn(p[0], sc.Wm[0], __fmaf_rn(p[1], sc.Wm[1], __fmaf_rn(p[2], sc.Wm[2], sc.Wm[3])));
+  const float lxx = __fmaf_rn(p[0], sc.Xm[0], __fmaf_rn(p[1], sc.Xm[1], __fmaf_rn(p[2], sc.Xm[2], sc.Xm[3])));
+  const float lyy = __fmaf_rn(p[0], sc.Ym[0], __fmaf_rn(p[1], sc.Ym[1], __fmaf_rn(p[2], sc.Ym[2], sc.Ym[3])));
+  float shadow[3];
+  shadow_lookup<COH>(Q.Lprev, sc.LB, __fmaf_rn(__fdiv_rn(lxx, lw), sc.lscale, sc.lbias),
+                     __fmaf_rn(__fdiv_rn(lyy, lw), sc.lscale, sc.lbias), shadow);
+  const float4 src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1, shadow);
+  if (sc.front_to_back) {
+    const float w = 1.0f - C.w;
+    C.x = __fmaf_rn(w, src.x, C.x);
+    C.y = __fmaf_rn(w, src.y, C.y);
+    C.z = __fmaf_rn(w, src.z, C.z);
+    C.w = __fmaf_rn(w, src.w, C.w);
+  } else {
+    const float w = 1.0f - src.w;
+    C.x = __fmaf_rn(w, C.x, src.x);
+    C.y = __fmaf_rn(w, C.y, src.y);
+    C.z = __fmaf_rn(w, C.z, src.z);
+    C.w = __fmaf_rn(w, C.w, src.w);
+  }
+  shadow_st4<COH>(P.out + o, C);
+}
+
+// one light-buffer texel of one slice: carried over, with the slice's sample on the texel's light ray laid over it
+template <int DT, int TF, bool COH = false>
+__device__ __forceinline__ void shadow_light_texel(const RenderParams &P, const ShadowSlice &Q, int x, int y) {
+  const smk_shadowcoef &sc = Q.sc;
+  if (x >= sc.LB || y >= sc.LB) return;
+  const size_t o = (size_t)y * sc.LB + x;
+  float4 L = shadow_ld4<COH>(Q.Lprev + o);
+  const float a = __fmaf_rn((float)x + 0.5f, sc.las, sc.lal), bb = __fmaf_rn((float)y + 0.5f, sc.las, sc.lal);
+  const float nG = __fmaf_rn(a, sc.nGx, __fmaf_rn(bb, sc.nGy, sc.nGc));
+  const float w = __fdiv_rn(Q.lnum, nG);
+  bool in = w > 0.0f && !isinf(w);
+  float p[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const float G = __fmaf_rn(a, sc.Gx[q], __fmaf_rn(bb, sc.Gy[q], sc.Gc[q]));
+    p[q] = __fmaf_rn(w, G, sc.Lc[q]);
+    in = in && p[q] >= -0.5f && p[q] <= (float)P.N[q] - 0.5f;
+  }
+  if (in && !shadow_brick_empty(P, p[0], p[1], p[2])) {
+    float ch0, ch1, ch2, ch3, n0, n1, n2;
+    shadow_fetch<DT, TF, false>(P, p[0], p[1], p[2], ch0, ch1, ch2, ch3, n0, n1, n2);
+    float4 col;
+    if (shadow_maybe_visible<TF>(P, ch0, ch1) && smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col)) {
+      // LERP r0.a, r0, r5 (saturated); alpha = sat((1 - a) r5.a + a)   (R8kVolRen3D.cpp:3150-3165)
+      const float al = col.w;
+      L.x = smk_sat(__fmaf_rn(al, smk_sat(col.x) - L.x, L.x));
+      L.y = smk_sat(__fmaf_rn(al, smk_sat(col.y) - L.y, L.y));
+      L.z = smk_sat(__fmaf_rn(al, smk_sat(col.z) - L.z, L.z));
+      L.w = smk_sat(__fmaf_rn(1.0f - al, L.w, al));
+    }
+  }
+  shadow_st4<COH>(Q.Lnext + o, L);
+}
+
 template <int DT, int TF, int SH>
 __global__ __launch_bounds__(256) void smk_k_shadow_slice(const RenderParams P, const ShadowSlice Q) {
-  const smk_shadowcoef &sc = Q.sc;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // a workgroup = 16x16 pixels, each wave an 8x8 sub-tile (compact footprints in the volume)
   const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
   if ((int)blockIdx.x < Q.eye_blocks) {
-    // ------------------------------------------------------------------ eye pass
-    const int i = ((int)blockIdx.x % Q.eye_bx) * 16 + lx, j = ((int)blockIdx.x / Q.eye_bx) * 16 + ly;
-    if (i >= P.W || j >= P.H) return;
-    const float px = __fmaf_rn((float)i + 0.5f, sc.pxs, sc.pxl), py = __fmaf_rn((float)j + 0.5f, sc.pys, sc.pyl);
-    const float nD = __fmaf_rn(px, sc.nDx, __fmaf_rn(py, sc.nDy, sc.nDc));
-    const float tau = __fdiv_rn(Q.num, nD);
-    if (!(tau > 0.0f) || isinf(tau)) return;
-    float p[3];
-    bool in = true;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float D = __fmaf_rn(px, sc.Dx[a], __fmaf_rn(py, sc.Dy[a], sc.Dc[a]));
-      p[a] = __fmaf_rn(tau, D, sc.Ec[a]);
-      in = in && p[a] >= -0.5f && p[a] <= (float)P.N[a] - 0.5f;
-    }
-    if (!in) return;
-    const size_t o = (size_t)j * P.W + i;
-    float4 C = P.out[o];
-    if (sc.front_to_back && C.w == 1.0f) return;  // exact: every later weight (1-A) is 0
-    if (shadow_brick_empty(P, p[0], p[1], p[2])) return;
-    float ch0, ch1, ch2, ch3, n0 = 0.f, n1 = 0.f, n2 = 0.f;
-    shadow_fetch<DT, TF, SH != 0>(P, p[0], p[1], p[2], ch0, ch1, ch2, ch3, n0, n1, n2);
-    float4 col;
-    if (!shadow_maybe_visible<TF>(P, ch0, ch1)) return;
-    if (!smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col)) return;
-    // (the light-buffer texels depend on the position alone and could be requested before the voxels are classified,
-    //  shortening the chain of dependent gathers; measured: 12.28 vs 10.95 ms per 512-slice frame -- nine lookups in
-    //  ten are then made for transparent samples, and the slice is bound by gather throughput, not by latency)
-    const float lw = __fmaf_rn(p[0], sc.Wm[0], __fmaf_rn(p[1], sc.Wm[1], __fmaf_rn(p[2], sc.Wm[2], sc.Wm[3])));
-    const float lxx = __fmaf_rn(p[0], sc.Xm[0], __fmaf_rn(p[1], sc.Xm[1], __fmaf_rn(p[2], sc.Xm[2], sc.Xm[3])));
-    const float lyy = __fmaf_rn(p[0], sc.Ym[0], __fmaf_rn(p[1], sc.Ym[1], __fmaf_rn(p[2], sc.Ym[2], sc.Ym[3])));
-    float shadow[3];
-    shadow_lookup(Q.Lprev, sc.LB, __fmaf_rn(__fdiv_rn(lxx, lw), sc.lscale, sc.lbias),
-                  __fmaf_rn(__fdiv_rn(lyy, lw), sc.lscale, sc.lbias), shadow);
-    const float4 src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1, shadow);
-    if (sc.front_to_back) {
-      const float w = 1.0f - C.w;
-      C.x = __fmaf_rn(w, src.x, C.x);
-      C.y = __fmaf_rn(w, src.y, C.y);
-      C.z = __fmaf_rn(w, src.z, C.z);
-      C.w = __fmaf_rn(w, src.w, C.w);
-    } else {
-      const float w = 1.0f - src.w;
-      C.x = __fmaf_rn(w, C.x, src.x);
-      C.y = __fmaf_rn(w, C.y, src.y);
-      C.z = __fmaf_rn(w, C.z, src.z);
-      C.w = __fmaf_rn(w, C.w, src.w);
-    }
-    P.out[o] = C;
+    shadow_eye_pixel<DT, TF, SH>(P, Q, ((int)blockIdx.x % Q.eye_bx) * 16 + lx, ((int)blockIdx.x / Q.eye_bx) * 16 + ly);
   } else {
-    // ------------------------------------------------------------------ light pass
     const int b = (int)blockIdx.x - Q.eye_blocks;
-    const int x = (b % Q.light_bx) * 16 + lx, y = (b / Q.light_bx) * 16 + ly;
-    if (x >= sc.LB || y >= sc.LB) return;
-    const size_t o = (size_t)y * sc.LB + x;
-    float4 L = Q.Lprev[o];
-    const float a = __fmaf_rn((float)x + 0.5f, sc.las, sc.lal), bb = __fmaf_rn((float)y + 0.5f, sc.las, sc.lal);
-    const float nG = __fmaf_rn(a, sc.nGx, __fmaf_rn(bb, sc.nGy, sc.nGc));
-    const float w = __fdiv_rn(Q.lnum, nG);
-    bool in = w > 0.0f && !isinf(w);
-    float p[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const float G = __fmaf_rn(a, sc.Gx[q], __fmaf_rn(bb, sc.Gy[q], sc.Gc[q]));
-      p[q] = __fmaf_rn(w, G, sc.Lc[q]);
-      in = in && p[q] >= -0.5f && p[q] <= (float)P.N[q] - 0.5f;
-    }
-    if (in && !shadow_brick_empty(P, p[0], p[1], p[2])) {
-      float ch0, ch1, ch2, ch3, n0, n1, n2;
-      shadow_fetch<DT, TF, false>(P, p[0], p[1], p[2], ch0, ch1, ch2, ch3, n0, n1, n2);
-      float4 col;
-      if (shadow_maybe_visible<TF>(P, ch0, ch1) && smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col)) {
-        // LERP r0.a, r0, r5 (saturated); alpha = sat((1 - a) r5.a + a)   (R8kVolRen3D.cpp:3150-3165)
-        const float al = col.w;
-        L.x = smk_sat(__fmaf_rn(al, smk_sat(col.x) - L.x, L.x));
-        L.y = smk_sat(__fmaf_rn(al, smk_sat(col.y) - L.y, L.y));
-        L.z = smk_sat(__fmaf_rn(al, smk_sat(col.z) - L.z, L.z));
-        L.w = smk_sat(__fmaf_rn(1.0f - al, L.w, al));
+    shadow_light_texel<DT, TF>(P, Q, (b % Q.light_bx) * 16 + lx, (b / Q.light_bx) * 16 + ly);
+  }
+}
+
+// ALL slices in one launch: a grid that fits the chip at once (cooperative launch: the runtime refuses one that does
+// not), every workgroup takes its share of each slice's eye and light blocks, and a grid-wide barrier stands where the
+// launch boundary was -- the light buffer slice k reads is complete, and visible on every XCD, before anybody starts
+// slice k + 1.  The same arithmetic per pixel and texel as the per-slice launches: identical frames and light buffers.
+// 512 launches of ~11 us each were the larger part of a frame with shadows (5.7 ms); the barrier is a fence and one
+// atomic round per workgroup.
+template <int DT, int TF, int SH>
+__global__ __launch_bounds__(256) void smk_k_shadow_fused(const RenderParams P, ShadowSlice Q, float4 *L0, float4 *L1, unsigned *barrier) {
+  const smk_shadowcoef &sc = Q.sc;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
+  const int nlb = Q.light_bx * Q.light_bx, nblocks = Q.eye_blocks + nlb;
+  for (int k = 1; k <= sc.nslices; ++k) {
+    Q.num = __fmaf_rn((float)k, sc.dnum, sc.num0);
+    Q.lnum = __fmaf_rn((float)k, sc.ldnum, sc.lnum0);
+    Q.Lprev = (k & 1) ? L0 : L1;
+    Q.Lnext = (k & 1) ? L1 : L0;
+    // (the light blocks first: every one of them has work -- a texel is always carried over -- while most eye blocks of a
+    //  slice leave at once)
+    for (int b = (int)blockIdx.x; b < nblocks; b += (int)gridDim.x) {
+      if (b < nlb) shadow_light_texel<DT, TF, true>(P, Q, (b % Q.light_bx) * 16 + lx, (b / Q.light_bx) * 16 + ly);
+      else {
+        const int e = b - nlb;
+        shadow_eye_pixel<DT, TF, SH, true>(P, Q, (e % Q.eye_bx) * 16 + lx, (e / Q.eye_bx) * 16 + ly);
       }
     }
-    Q.Lnext[o] = L;
+    // grid barrier: every wave's device-scope stores have been acknowledged (vmcnt 0) before its workgroup signs in; one
+    // counter, monotone (slice k waits for k * gridDim.x arrivals); the cooperative launch guarantees that every workgroup
+    // is resident, the spin is bounded all the same (a barrier that cannot complete leaves the frame wrong, never the GPU hung)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      // two levels: the workgroups of an XCD (blockIdx % 8) count into their own word, the last of each XCD into the common
+      // one, and everybody polls the common word -- 8 + gridDim.x / 8 arrivals per word instead of gridDim.x on one
+      const unsigned xcd = blockIdx.x & 7u, per_xcd = (gridDim.x + 7u - xcd) / 8u;
+      const unsigned mine = __hip_atomic_fetch_add(barrier + 16 * (1 + xcd), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+      if (mine == (unsigned)k * per_xcd) __hip_atomic_fetch_add(barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned want = (unsigned)k * min(gridDim.x, 8u);
+      for (int spins = 0; spins < (1 << 22); ++spins) {
+        if (__hip_atomic_load(barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+        __builtin_amdgcn_s_sleep(8);
+      }
+    }
+    __syncthreads();
   }
 }
 
 template <int DT, int TF, int SH>
-static hipError_t run(const RenderParams &P, ShadowSlice Q, float4 *L0, float4 *L1, hipStream_t s) {
+static hipError_t run(const RenderParams &P, ShadowSlice Q, float4 *L0, float4 *L1, unsigned *barrier, hipStream_t s) {
   const smk_shadowcoef &sc = Q.sc;
   Q.eye_bx = (P.W + 15) / 16;
   Q.eye_blocks = Q.eye_bx * ((P.H + 15) / 16);
   Q.light_bx = (sc.LB + 15) / 16;
   const int blocks = Q.eye_blocks + Q.light_bx * Q.light_bx;
+  // one cooperative launch for all slices where the device offers it (SMK_SHADOW_FUSED=0: the per-slice launches)
+  // Measured on one MI355X (cfg 3 with shadows, 512 slices): per-slice launches 5.56 ms per frame; the fused launch 12.8 /
+  // 16.3 / 20.2 ms with 2 / 4 / 8 workgroups per CU (two-level barrier with back-off; a single counter: 26 / 40 / 50 ms;
+  // cooperative_groups' grid.sync() with its device-wide cache write-back and invalidate: 67 ms).  Few resident workgroups
+  // walk a slice's 5120 blocks one after the other, each a chain of dependent gathers, where a launch has them all in
+  // flight; many make the barrier -- every workgroup polling one word through the fabric -- cost more than the ~11 us launch
+  // it replaces.  The hardware's dispatcher IS the cheaper barrier here: the fused form stays an option ("shadow_fused").
+  const bool want_fused = (P.lockstep & 256) != 0;
+  if (want_fused) {
+    int dev = 0, coop = 0, per_cu = 0, cus = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (coop && cus > 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, smk_k_shadow_fused<DT, TF, SH>, 256, 0) == hipSuccess && per_cu > 0) {
+      // (a barrier costs with the number of workgroups that meet at it: four per CU hide the gathers' latency, more only wait)
+      static const int wgs_per_cu = getenv("SMK_SHADOW_WGS") ? std::max(1, atoi(getenv("SMK_SHADOW_WGS"))) : 4;  // (developer knob)
+      const int grid = std::min(blocks, cus * std::min(per_cu, wgs_per_cu));
+      RenderParams Pa = P;
+      ShadowSlice Qa = Q;
+      unsigned *bar = barrier;  // (the context's word, zeroed on the stream before every frame)
+      if (bar && hipMemsetAsync(bar, 0, 16 * 9 * 4, s) != hipSuccess) bar = nullptr;
+      void *args[] = {(void *)&Pa, (void *)&Qa, (void *)&L0, (void *)&L1, (void *)&bar};
+      if (bar) {
+      const hipError_t e = hipLaunchCooperativeKernel((const void *)smk_k_shadow_fused<DT, TF, SH>, dim3(grid), dim3(256), args, 0, s);
+      if (e == hipSuccess) return hipGetLastError();
+      (void)hipGetLastError();  // refused (resources): the per-slice launches below
+      }
+    }
+  }
   for (int k = 1; k <= sc.nslices; ++k) {
     Q.num = fmaf((float)k, sc.dnum, sc.num0);
     Q.lnum = fmaf((float)k, sc.ldnum, sc.lnum0);
@@ -226,12 +342,12 @@ static hipError_t run(const RenderParams &P, ShadowSlice Q, float4 *L0, float4 *
 
 // L0 must be cleared by the caller; after the call the light buffer is L1 for odd nslices, L0 for even ones
 hipError_t smk_launch_shadow(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, int shade_kind,
-                             float4 *L0, float4 *L1, hipStream_t s) {
+                             float4 *L0, float4 *L1, unsigned *barrier, hipStream_t s) {
   ShadowSlice Q;
   memset(&Q, 0, sizeof Q);
   Q.sc = sc;
 #define CASE(D, T, S) \
-  if (dtype == D && tf_mode == T && shade_kind == S) return run<D, T, S>(P, Q, L0, L1, s);
+  if (dtype == D && tf_mode == T && shade_kind == S) return run<D, T, S>(P, Q, L0, L1, barrier, s);
   CASE(0, 1, 0) CASE(0, 1, 1) CASE(0, 2, 0) CASE(0, 2, 1)
   CASE(1, 1, 0) CASE(1, 1, 1) CASE(1, 2, 0) CASE(1, 2, 1)
 #undef CASE

@@ -124,3 +124,23 @@ def test_unsupported_combinations_fail_with_the_reason(R, smk, gpu_renderer_fact
     finally:
         r2.close()
     R.set_shadow(0)
+
+
+def test_all_slices_in_one_cooperative_launch(R):
+    """Option shadow_fused: the slices of a frame as ONE launch with a grid barrier between them, the frame and the light
+    buffer accessed at device scope.  Slower than a launch per slice on MI355X, kept as an option: the same
+    arithmetic, so frame and light buffer are bit-identical to the per-slice launches'."""
+    sc = make_scene("cfg4", n=64, size=160, steps=200, f32=True, shade=1, pose="diag")
+    sc.light_pos = LIGHTS["oblique"]
+    sc.shadow = (512, 0.5)
+    push_scene(R, sc)
+    a = R.render()
+    la = R.light_buffer()
+    R.set_option("shadow_fused", 1)
+    try:
+        b = R.render()
+        lb = R.light_buffer()
+    finally:
+        R.set_option("shadow_fused", 0)
+    assert R.last_frame_info()[0] == 3
+    assert np.array_equal(a, b) and np.array_equal(la, lb)
