@@ -124,7 +124,8 @@ int smk_set_region(smk_ctx *ctx, int on, const float lo[3], const float hi[3]);
 /* replaces the clip widget's free mode: glClipPlane(GL_CLIP_PLANE5, {0,0,-1,0}) specified under the
  * modelview wmv * T(clip.pos) * clip.xform (NV20VolRen3D.cpp:346-357; R8kVolRen3D.cpp:780-794).
  * plane_eye = the eye-space plane OpenGL stores for that call ({0,0,-1,0} times the inverse of that
- * matrix); a sample stays when plane_eye . (x_eye, 1) >= 0.  Frames with it run on the gather kernel. */
+ * matrix); a sample stays when plane_eye . (x_eye, 1) >= 0.  Both ray-marchers take it (the slice-ring kernel folds it
+ * into each ray's plane interval: nothing per sample). */
 int smk_set_clip_plane(smk_ctx *ctx, int on, const double plane_eye[4]);
 /* replaces R8kVolRen3D_cpy::createNoiseTex + gluvv.pert (R8kVolRen3D_cpy.cpp:2392-2480,
  * 1590-1595): n^3 RGBA8 noise (GL_REPEAT), weights/scales of the two live octaves. noise NULL

@@ -345,6 +345,21 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       empty = true;
     }
   }
+  // Free clip plane (glClipPlane, NV20VolRen3D.cpp:346-357): fragments on its negative side do not exist.  The plane's value
+  // along a ray, cplane . (p(q), 1), is monotone in the plane index q like the coordinates: the kept samples are an interval
+  // that ends where it crosses zero -- folded into the ray's range HERE, the marching loop never hears of it (as a test per
+  // sample in the loop it cost every frame without a clip plane 4-5 %: round 2).
+  if (P.cplane_on) {
+    const float c0 = __fmaf_rn(A[0], P.cplane[0], __fmaf_rn(A[1], P.cplane[1], __fmaf_rn(A[2], P.cplane[2], P.cplane[3])));
+    const float c1 = __fmaf_rn(B[0], P.cplane[0], __fmaf_rn(B[1], P.cplane[1], B[2] * P.cplane[2]));
+    if (fabsf(c1) > 1e-20f) {
+      const float tz = -c0 / c1;  // the crossing, in planes
+      if (c1 > 0.0f) tenter = fmaxf(tenter, tz - 2.0f);
+      else texit = fminf(texit, tz + 2.0f);
+    } else if (!(c0 >= 0.0f)) {
+      empty = true;
+    }
+  }
   int m = (int)floorf(fmaxf(tenter, 0.0f));
   int m1 = (int)ceilf(fminf(texit, (float)(rc.nplanes - 1)));
   if (empty || !(tenter <= texit)) m1 = m - 1;
@@ -358,8 +373,11 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
     auto inside = [&](int q) -> bool {
       const float qf = (float)q;
       const float p0 = __fmaf_rn(qf, B[0], A[0]), p1 = __fmaf_rn(qf, B[1], A[1]), p2 = __fmaf_rn(qf, B[2], A[2]);
-      return ((int)(smk_clampf(p0, P.lo[0], P.hin[0]) == p0) & (int)(smk_clampf(p1, P.lo[1], P.hin[1]) == p1) &
-              (int)(smk_clampf(p2, P.lo[2], P.hin[2]) == p2)) != 0;
+      bool in = ((int)(smk_clampf(p0, P.lo[0], P.hin[0]) == p0) & (int)(smk_clampf(p1, P.lo[1], P.hin[1]) == p1) &
+                 (int)(smk_clampf(p2, P.lo[2], P.hin[2]) == p2)) != 0;
+      // (the gather kernel's own fma chain for the plane: the same samples pass, bit for bit)
+      if (P.cplane_on) in = in && __fmaf_rn(p0, P.cplane[0], __fmaf_rn(p1, P.cplane[1], __fmaf_rn(p2, P.cplane[2], P.cplane[3]))) >= 0.0f;
+      return in;
     };
     int mf = m1 + 1, ml = m - 1;
     int qa = m, qb = m1;
@@ -1787,9 +1805,8 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
   if (Q.perm == 0) { Q.strideV = P.D[0]; Q.strideS = (long long)P.D[0] * P.D[1]; Q.vox = vox_native; }
   else if (Q.perm == 1) { Q.strideV = (long long)P.D[0] * P.D[1]; Q.strideS = P.D[0]; Q.vox = vox_native; }
   else { Q.strideV = P.D[1]; Q.strideS = (long long)P.D[1] * P.D[2]; Q.vox = vox_xmajor; }  // [x][z][y]
-  // (the test as a run-time branch in the consumers was built and measured: frames identical to the gather kernel's, but
-  //  every frame WITHOUT a clip plane paid 4-5 % at 512^3 and 2 % at 1024^3 for the scalar registers it holds)
-  if (P.cplane_on) { *why = "free clip plane (a per-sample half-space test: gather kernel)"; return hipErrorNotSupported; }
+  // (the free clip plane lives in the kernel's set-up: the kept samples of a ray are an interval of planes, see there; as a
+  //  run-time test per sample in the consumers' loop it cost every frame WITHOUT a clip plane 4-5 % at 512^3 -- round 2)
   // an empty region (a clip plane outside a shard's box): the gather kernel's explicit comparisons
   // render it as nothing; the median-of-three membership test here needs lo <= hi
   for (int a = 0; a < 3; ++a)

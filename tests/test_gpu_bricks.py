@@ -115,7 +115,8 @@ def test_ragged_and_thin(R):
 
 
 def test_depth_and_clip_plane_frames_on_the_gather_kernel(R):
-    """frames only the gather kernel renders (first-hit depth, a free clip plane): flags on == flags off, depth included"""
+    """a frame only the gather kernel renders (first-hit depth requested, here with a free clip plane): flags on == flags
+    off, depth included"""
     sc = make_scene("cfg3", n=64, size=96, steps=128, pose="rot", f32=True, shade=1)
     n = np.array([0.35, -0.2, -0.9])
     n /= np.linalg.norm(n)

@@ -310,29 +310,33 @@ def test_clip_plane_outside_a_shard_leaves_it_empty(gpu_renderer_factory):
         r.close()
 
 
-@pytest.mark.parametrize("pose", ["rot", "z-"])
-def test_free_clip_plane_runs_on_the_gather_kernel(R, pose):
-    """gluvv.clip in its free mode = glClipPlane under the widget's matrix (NV20VolRen3D.cpp:346-357):
-    a per-sample half-space test in eye space.  The gather kernel takes it; the slice-ring kernel,
-    whose rays know their inside interval from an axis-aligned box, declines."""
-    sc = make_scene("cfg2", n=32, size=64, steps=72, pose=pose, f32=True, shade=1)
+@pytest.mark.parametrize("pose", ["rot", "z-", "x+", "y-"])
+@pytest.mark.parametrize("f32", [True, False])
+def test_free_clip_plane_on_the_slice_ring_kernel(R, pose, f32):
+    """gluvv.clip in its free mode = glClipPlane under the widget's matrix (NV20VolRen3D.cpp:346-357): a half-space in
+    eye space.  Along a ray the plane's value is monotone in the plane index, so the kept samples are an interval: the
+    slice-ring kernel folds it into each ray's plane range in its set-up (nothing in the marching loop) and renders the
+    frame bit for bit like the gather kernel's per-sample test, with and without the brick flags, split in depth or not."""
+    sc = make_scene("cfg2", n=32, size=64, steps=72, pose=pose, f32=f32, shade=1)
     whole = sc.render()
     n = np.array([0.35, -0.2, -0.9])
     n /= np.linalg.norm(n)
     mv = np.array(sc.mv(), np.float64).reshape(4, 4).T   # column-major -> rows
     centre = mv @ np.array([float(sc.fsize[0]) / 2, float(sc.fsize[1]) / 2, float(sc.fsize[2]) / 2, 1.0])
-    sc.clip_plane = (n[0], n[1], n[2], -float(n @ centre[:3]) + 0.03)   # through (almost) the volume's middle
-    ref = sc.render()
-    assert np.abs(ref - whole).max() > 0.02 and ref[..., 3].max() > 0.05
-    push_scene(R, sc)
-    R.set_option("kernel", 0)
-    img = R.render()
-    assert R.last_frame_info()[0] == 1
-    assert np.abs(img - ref).max() <= TOL
-    R.set_option("kernel", 2)
-    with pytest.raises(Exception, match="free clip plane"):
-        R.render()
-    R.set_option("kernel", 0)
+    for off, flip in ((0.03, 1.0), (-0.11, -1.0), (0.6, 1.0), (-0.6, 1.0)):     # through the middle, the other side, nothing cut, everything cut
+        sc.clip_plane = tuple(flip * v for v in (n[0], n[1], n[2], -float(n @ centre[:3]) + off))
+        ref = sc.render()
+        a, b = _both(R, sc)
+        assert np.array_equal(a, b), "slab and gather kernels differ: %g" % np.abs(a - b).max()
+        assert np.abs(b - ref).max() <= TOL
+        if abs(off) < 0.2:
+            assert np.abs(ref - whole).max() > 0.02 and ref[..., 3].max() > 0.05
+    R.set_option("slab_split", 3)
+    try:
+        a, b = _both(R, sc)
+        assert np.abs(a - b).max() <= 2e-5
+    finally:
+        R.set_option("slab_split", 0)
     sc.clip_plane = None
     a, b = _both(R, sc, upload=False)
     assert np.array_equal(a, b) and np.abs(b - whole).max() <= TOL
