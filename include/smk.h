@@ -324,9 +324,12 @@ int smk_timing_read(smk_ctx *ctx, float *avg_ms, int *nframes);
  * lockstep has bit 16 set), "slab_status" (these synchronise the device); "slab_failures",
  * "slab_retries" (host-side counters, no synchronisation). */
 int smk_get_stat(smk_ctx *ctx, const char *name, double *value);
-/* workgroup timeline of the last frame rendered with option lockstep bit 32 (developer tool):
+/* workgroup timeline of the last slice-ring frame (developer tool):
  * records of 8 x uint32 {start, end (100 MHz ticks), HW_ID, XCC_ID | tile<<8 | slices<<20, loader 0's
  * issue / vmcnt-wait / ring-blocked time in units of 64 cycles, sum of the consumer waves' iterations};
+ * with option lockstep bit 32 set the records come from the diagnostic kernel instances, one per workgroup;
+ * without it from the product kernel itself, one per tile (the first four words; a tile cut in depth segments
+ * leaves its record empty).
  * *nrecords = records available; copies min(cap_records, *nrecords) when out != NULL. */
 int smk_get_trace(smk_ctx *ctx, unsigned *out, int cap_records, int *nrecords);
 /* effective 2-D TF after opacity correction, as uploaded (sg*sv*4 bytes) */

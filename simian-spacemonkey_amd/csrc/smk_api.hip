@@ -1414,6 +1414,25 @@ extern "C" int smk_get_stat(smk_ctx *c, const char *name, double *value) {
 extern "C" int smk_get_trace(smk_ctx *c, unsigned *out, int cap_records, int *nrecords) {
   if (!c || !nrecords) return 1;
   HIPCHK(c, hipSetDevice(c->device));
+  if (!(c->opt_lockstep & 32)) {
+    // no diagnostic instance ran: the product kernel's own words per tile (start, duration, where) in the same record shape
+    const int nt = c->last_kernel == 2 && c->slab.d_ticks ? c->slab.ticks_n_last : 0;
+    *nrecords = nt;
+    if (out && nt > 0) {
+      HIPCHK(c, hipDeviceSynchronize());
+      std::vector<unsigned> h((size_t)nt * 5);
+      HIPCHK(c, hipMemcpy(h.data(), c->slab.d_ticks, (size_t)nt * 20, hipMemcpyDeviceToHost));
+      for (int t = 0; t < std::min(cap_records, nt); ++t) {
+        unsigned *r = out + (size_t)t * 8;
+        r[0] = h[(size_t)3 * nt + t];
+        r[1] = h[(size_t)3 * nt + t] ? r[0] + h[t] : 0u;   // (a tile cut in depth segments has no start word: record left empty)
+        r[2] = h[(size_t)4 * nt + t] & 0xff00u;
+        r[3] = (h[(size_t)4 * nt + t] & 0xfu) | ((unsigned)t << 8) | (h[(size_t)2 * nt + t] << 20);
+        r[4] = r[5] = r[6] = r[7] = 0;
+      }
+    }
+    return 0;
+  }
   *nrecords = c->slab.d_trace ? c->slab.trace_n : 0;
   if (out && *nrecords > 0) {
     HIPCHK(c, hipDeviceSynchronize());

@@ -68,7 +68,7 @@ struct SlabParams {
   int bsu, bsv, bss;           // their strides along U, V, S (in bricks)
   const int2 *order;           // workgroup of each block: {tile | piece << 20 | pieces << 26, cut fractions lo | hi << 8} (work-balanced
                                // schedule, .x = -1: none), see smk_launch_slab and DEPTH SEGMENTS
-  unsigned *tile_ticks;        // [3][ntiles]: duration of each tile's workgroup in 100 MHz ticks (next frame's weights) |
+  unsigned *tile_ticks;        // [5][ntiles]: duration of each tile's workgroup in 100 MHz ticks (next frame's weights) |
                                // slices its loaders streamed | slices of its range (the loaders stop once every ray of
                                // the tile is saturated: what was NOT streamed is not counted as read, smk_last_frame_info)
   int ntiles;
@@ -1456,6 +1456,9 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
     // (less the slices that were not streamed because nobody samples them: EMPTY LAYERS)
     Q.tile_ticks[Q.ntiles + tile] = npos > 0 ? (unsigned)max(min(max(min(min(ctl[4], ctl[5]), min(ctl[6], ctl[7])), 0), npos + 1) - ctl[2], 0) : 0u;
     Q.tile_ticks[2 * Q.ntiles + tile] = npos > 0 ? (unsigned)(npos + 1) : 0u;
+    // (the product's own timeline, read by smk_get_trace when no diagnostic instance ran: when the workgroup started, and where)
+    Q.tile_ticks[3 * Q.ntiles + tile] = trace_t0;
+    Q.tile_ticks[4 * Q.ntiles + tile] = (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xff00u) | (__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xfu);
   }
   if (tracing && tid == 0) {
     unsigned *t = Q.trace + 8 * (size_t)blockIdx.x;
@@ -2164,9 +2167,9 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
         if (aux->h_pticks) (void)hipHostFree(aux->h_pticks);
         aux->d_pticks = nullptr;
         aux->h_pticks = nullptr;
-        hipError_t e = hipMalloc((void **)&aux->d_ticks, (size_t)nt * 12);
+        hipError_t e = hipMalloc((void **)&aux->d_ticks, (size_t)nt * 20);
         if (e != hipSuccess) return e;
-        e = hipMemset(aux->d_ticks, 0, (size_t)nt * 12);
+        e = hipMemset(aux->d_ticks, 0, (size_t)nt * 20);
         if (e != hipSuccess) return e;
         e = hipHostMalloc((void **)&aux->h_ticks, (size_t)nt * 4, hipHostMallocDefault);
         if (e != hipSuccess) return e;
@@ -2321,9 +2324,32 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
         //  of host time whenever new weights arrived.)
         std::vector<std::vector<int>> run(8);
         size_t longest = 0;
+        const bool dealt = opt_sched == 0;
+        if (dealt) {
+          // DEALT (round 3; the runs above stay as option slab_sched 5): tiles in order of falling weight, each to the XCD
+          // that carries the least so far -- every XCD gets the same mix of long and short workgroups.  The dispatcher hands
+          // blocks out in index order, block b to XCD b % 8, and a block whose XCD has no free slot holds back every block
+          // behind it: the XCDs' lists advance in step, entry k of all eight together.  With a contiguous run of the image
+          // per XCD the lists differ (166-240 tiles, the centre's runs hold more long tiles than an XCD has slots: two of
+          // them must share a slot) and slots stood idle for a mean 10 us per turnover while work was pending elsewhere
+          // (tools/timeline.py).  Dealt: cfg 3 0.609 -> 0.587 ms, the 1024^3 frame 1.176 -> 1.109; with every slice streamed
+          // (equal tiles) no change.
+          std::vector<int> idx((size_t)nt);
+          for (int t = 0; t < nt; ++t) idx[t] = t;
+          std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return work[a] > work[b]; });
+          long long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          for (int t : idx) {
+            int x = 0;
+            for (int k = 1; k < 8; ++k)
+              if (load[k] < load[x]) x = k;
+            run[x].push_back(t);
+            load[x] += work[t];
+          }
+        }
         for (int x = 0; x < 8; ++x) {
-          for (int t = cut[x]; t < cut[x + 1]; ++t) run[x].push_back(seq[t]);
-          if (opt_sched == 0) {
+          if (!dealt)
+            for (int t = cut[x]; t < cut[x + 1]; ++t) run[x].push_back(seq[t]);
+          if (opt_sched == 0 || opt_sched == 5) {
             // (a split tile's pieces weigh a share each: they sort behind the unsplit tiles of their tile's full weight)
             std::stable_sort(run[x].begin(), run[x].end(), [&](int a, int b) { return work[a] / ksplit[a] > work[b] / ksplit[b]; });
           } else {
@@ -2354,7 +2380,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
             for (int k = 0; k < c[0]; ++k)
               items[x].push_back({piece_weight(t, k), make_int2(t | (k << 20) | ((int)c[0] << 26), (int)c[1 + k] | ((int)c[2 + k] << 8))});
           }
-          if (opt_sched == 0) std::stable_sort(items[x].begin(), items[x].end(), [](const std::pair<int, int2> &a, const std::pair<int, int2> &b) { return a.first > b.first; });
+          if (opt_sched == 0 || opt_sched == 5) std::stable_sort(items[x].begin(), items[x].end(), [](const std::pair<int, int2> &a, const std::pair<int, int2> &b) { return a.first > b.first; });
           longest = std::max(longest, items[x].size());
         }
         order.assign(longest * 8, make_int2(-1, 0));
@@ -2466,7 +2492,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     const bool diag = (P.lockstep & ~1) != 0 && dtype == 1 && shade_kind == 1;
     const int nsplit_now = aux->nsplit_last, nblocks_now = aux->nblocks_last;
     if (nsplit_now > 0) {  // (their tick words are sums over the pieces)
-      hipError_t e = hipMemsetAsync(aux->d_ticks, 0, (size_t)ticks_n_now * 12, s);
+      hipError_t e = hipMemsetAsync(aux->d_ticks, 0, (size_t)ticks_n_now * 20, s);
       if (e != hipSuccess) return e;
     }
     const int mtw = tw, mth = th;
