@@ -145,8 +145,9 @@ int smk_set_perturb(smk_ctx *ctx, const unsigned char *noise_rgba, int n, const 
 int smk_set_shadow(smk_ctx *ctx, int on, int buffer_px, float quality);
 /* replaces the glBlendFunc / glBlendEquationEXT state of the slice loop (VolumeRenderer.cpp:589-590,
  * NV20VolRen3D.cpp:158-163, 930; R8kVolRen3D.cpp:1436-1449).  Default: front to back.  The two
- * "over" orders are the same operator evaluated from opposite ends (equal up to fp32 rounding);
- * back-to-front frames run on the gather kernel. */
+ * "over" orders are the same operator evaluated from opposite ends (equal up to fp32 rounding):
+ * the gather kernel (option "kernel" 1) walks the planes of a back-to-front frame from the far one, as
+ * the reference does; the slice-ring kernel composites such a frame front to back. */
 int smk_set_blend(smk_ctx *ctx, smk_blend mode);
 
 /* replaces gluvvPrimitive::draw() -> renderVolume (VolumeRenderer.cpp:280-328,
@@ -296,7 +297,8 @@ int smk_get_brick_flags(smk_ctx *ctx, unsigned char *flags_out, int *nb_out, int
  *   "slab_split" [0] depth segments of the slice-ring kernel: 0 = tiles measured long are rendered by several
  *              workgroups where the longest tile stands above the mean load of a workgroup slot (sharded
  *              contexts), the partial frames merged in order (<= 2e-5 from the unsplit frame); 1 = never
- *              (bit-identical to the gather kernel everywhere); 2..8 = every tile in that many
+ *              (bit-identical to the gather kernel everywhere); 2..8 = every tile in that many.  Frames with a
+ *              depth output are never cut (the merge pass knows colours only)
  *   "tf_raw"   [0] 1: the 2-D table handed to smk_set_tf2d is already opacity-corrected (copyScale off)
  *   "halo"     [1] voxels of halo kept around a shard's region (before smk_upload_volume)
  *   "bricks"   [1] empty-space skipping: 8x8x8-cell bricks in which no sample can be visible under the current

@@ -1371,6 +1371,9 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 #undef NB
               src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1);
             }
+            // first-hit depth (the gather kernel's `first`): the first sample that passes classification finds the accumulated
+            // alpha still exactly 0, no later one does -- nothing is carried through the loop for it
+            if (P.depth != nullptr && C3 == 0.0f) P.depth[(size_t)j * P.W + i] = __fmaf_rn((float)m, rc.dtau, rc.tau0) * P.znear;
             if (P.blend == SMK_BLEND_MAX) {  // GL_MAX (gluvvShadeMIP): no order, no termination
               C0 = fmaxf(C0, src.x);
               C1 = fmaxf(C1, src.y);
@@ -1438,6 +1441,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
     size_t o = (size_t)j * P.W + i;
     float4 *outp = seg == 0 ? P.out : Q.seg_out + (size_t)(seg - 1) * ((size_t)P.W * P.H);
     outp[o] = make_float4(C0, C1, C2, C3);
+    if (P.depth != nullptr && C3 == 0.0f) P.depth[o] = __int_as_float(0x7f800000);  // (no sample passed classification)
   }
   // errors are reported, never swallowed: the host turns a non-zero status into a failed frame
   if (npos > 0) {
@@ -1772,7 +1776,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
   const int opt_fly = (opt_T >> 8) & 0xff;  // (developer knobs travel packed: slab_T | slab_fly << 8 | slab_ns << 16 | slab_sched << 24)
   const int opt_ns = (opt_T >> 16) & 0xff;
   const int opt_sched = (opt_T >> 24) & 0xf;  // (experiment knob: order of an XCD's tiles, see the schedule)
-  const int opt_split = aux->opt_split;       // DEPTH SEGMENTS: 0 auto (measured long tiles), 1 off, 2.. every tile in that many
+  const int opt_split = P.depth ? 1 : aux->opt_split;  // DEPTH SEGMENTS: 0 auto (measured long tiles), 1 off, 2.. every tile in that many (a depth output: off -- the merge pass knows colours only)
   opt_T &= 0xff;
   *why = nullptr;
   if (tf_mode < 0 || tf_mode > 2) { *why = "no classification mode"; return hipErrorNotSupported; }
@@ -1780,8 +1784,9 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
   if (tf_mode == 0) shade_kind = 0;  // (the scalar renderer does not shade, VolumeRenderer.cpp:576-587)
   if (tf_mode == 2 && (!P.tf3d || P.s3v < 1 || P.s3g < 1 || P.s3h < 1)) { *why = "no 3-D table"; return hipErrorNotSupported; }
   if (P.pert_on) { *why = "perturbation"; return hipErrorNotSupported; }
-  if (P.blend == SMK_BLEND_BACK_TO_FRONT) { *why = "back-to-front blend (slices stream front to back)"; return hipErrorNotSupported; }
-  if (P.depth) { *why = "first-hit depth requested"; return hipErrorNotSupported; }  // (a register the fast path cannot spare)
+  // (back-to-front frames -- VolumeRenderer.cpp:590 -- are composited FRONT TO BACK here: "over" is associative, the slices
+  //  stream one way; what changes is the association of the blend -- a few ulp per sample, as with depth segments -- and a
+  //  saturated ray may stop.  Option kernel = 1 renders them in the reference's own order.)
   if (P.N[0] < 2 || P.N[1] < 2 || P.N[2] < 2) { *why = "volume thinner than 2 voxels"; return hipErrorNotSupported; }
   if (dtype == 1 && !P.n_in_w) { *why = "4-channel f32 voxels"; return hipErrorNotSupported; }
   if (P.rc.nplanes <= 0) { *why = "no planes"; return hipErrorNotSupported; }
@@ -2215,7 +2220,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
         };
         if (opt_split >= 2) {
           for (int t = 0; t < nt; ++t) equal_cuts(t, std::min(opt_split, 8));
-        } else if (opt_split == 0 && measured && P.blend != SMK_BLEND_BACK_TO_FRONT) {
+        } else if (opt_split == 0 && measured) {
           long long total = 0;
           for (int t = 0; t < nt; ++t) total += work[t];
           const double wg_slots = 256.0 * ((nw + nl) > SLAB_BIG_WAVES ? 1 : 2);

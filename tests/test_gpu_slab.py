@@ -52,25 +52,63 @@ def test_modes(R, kind, shade, f32):
     assert np.abs(b - ref).max() <= TOL
 
 
-def test_depth_request_uses_the_gather_kernel(R):
-    """First-hit depth is a register the slice-ring kernel does not spend: a frame that asks for
-    it runs on the gather kernel in auto mode (same RGBA, bit for bit) and is refused when the
-    slice-ring kernel is forced."""
-    sc = make_scene("cfg3", n=32, size=64, steps=64, pose="diag", f32=True, shade=1)
-    (ref, rd) = sc.render(depth=True)
+@pytest.mark.parametrize("kind,pose,f32,blend", [("cfg3", "diag", True, 0), ("cfg3", "rot", False, 0), ("cfg4", "side", True, 0),
+                                                  ("cfg3", "back", True, 2), ("cfg2", "diag", True, 0)])
+def test_first_hit_depth_on_the_slice_ring_kernel(R, kind, pose, f32, blend):
+    """First-hit depth (round 3): the first sample that passes classification finds the accumulated alpha exactly 0 -- the
+    slice-ring kernel stores the depth there and carries nothing through its loop for it.  Same depth as the gather
+    kernel bit for bit (the same fma of the same plane index), same RGBA as without the request, and the checker's."""
+    sc = make_scene(kind, n=32, size=64, steps=64, pose=pose, f32=f32, shade=1 if kind != "cfg2" else 0)
+    (ref, rd) = sc.render(depth=True, blend=blend)
     push_scene(R, sc)
-    R.set_option("kernel", 0)
-    rgba, dep = R.render(depth=True)
-    assert R.last_frame_info()[0] == 1
-    plain = R.render()
-    assert R.last_frame_info()[0] == 2
-    assert np.array_equal(rgba, plain)
-    fin = np.isfinite(rd)
-    assert np.array_equal(fin, np.isfinite(dep)) and np.abs(rd[fin] - dep[fin]).max() <= 1e-4
-    R.set_option("kernel", 2)
-    with pytest.raises(Exception, match="depth"):
-        R.render(depth=True)
-    R.set_option("kernel", 0)
+    R.set_blend(blend)
+    try:
+        R.set_option("kernel", 1)
+        ga, gd = R.render(depth=True)
+        R.set_option("kernel", 2)
+        sa, sd = R.render(depth=True)
+        assert R.last_frame_info()[0] == 2
+        plain = R.render()
+        assert np.array_equal(sa, plain) and np.array_equal(sa, ga)
+        assert np.array_equal(np.isfinite(gd), np.isfinite(sd))
+        fin = np.isfinite(gd)
+        assert fin.any() and not fin.all()
+        assert np.array_equal(gd[fin], sd[fin])
+        assert np.array_equal(fin, np.isfinite(rd)) and np.abs(rd[fin] - sd[fin]).max() <= 1e-4
+        assert np.abs(sa - ref).max() <= TOL
+    finally:
+        R.set_blend(0)
+        R.set_option("kernel", 0)
+
+
+@pytest.mark.parametrize("kind,pose,f32", [("cfg3", "diag", True), ("cfg3", "back", False), ("tf3d", "rot", True), ("cfg1", "side", False)])
+def test_back_to_front_frames_on_the_slice_ring_kernel(R, kind, pose, f32):
+    """Back-to-front frames (VolumeRenderer.cpp:590) are composited front to back by the slice-ring kernel: "over" is
+    associative, the slices stream one way.  Against the gather kernel, which walks the planes in the reference's order,
+    the blend is re-associated: a few ulp per sample (2e-5 asserted), the checker's tolerance against the checker; the
+    first-hit depth -- the nearest contributing sample either way -- is the same number."""
+    sc = make_scene(kind, n=32, size=64, steps=64, pose=pose, f32=f32, shade=1 if kind == "cfg3" else 0)
+    (ref, rd) = sc.render(depth=True, blend=1)
+    push_scene(R, sc)
+    R.set_blend(1)
+    try:
+        R.set_option("kernel", 1)
+        ga, gd = R.render(depth=True)
+        R.set_option("kernel", 2)
+        sa, sd = R.render(depth=True)
+        assert R.last_frame_info()[0] == 2
+        assert ref[..., 3].max() > 0.05
+        assert np.abs(sa - ga).max() <= 2e-5
+        assert np.abs(sa - ref).max() <= TOL
+        fin = np.isfinite(gd)
+        assert np.array_equal(fin, np.isfinite(sd)) and np.array_equal(gd[fin], sd[fin])
+        R.set_option("kernel", 0)       # auto mode may now choose either kernel for such frames
+        R.render()
+        R.render()
+        assert R.last_frame_info()[0] in (1, 2)
+    finally:
+        R.set_blend(0)
+        R.set_option("kernel", 0)
 
 
 @pytest.mark.parametrize("pose", ["z-", "y+", "x-"])
