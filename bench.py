@@ -51,7 +51,7 @@ def pmc_insts(workload):
     """Per-launch instruction counters of the ray-march kernel from the committed SQ passes
     (profiles/rNN_pmc_sq_<cfg3|ns>.txt, written by tools/profile_round.sh + tools/pmc_summary.py)."""
     d = os.path.join(ROOT, "profiles")
-    suffix = "_pmc_sq_%s.txt" % {"cfg3": "cfg3", "north_star": "ns", "cfg3_dense": "cfg3_dense", "north_star_dense": "ns_dense"}.get(workload, "ns")
+    suffix = "_pmc_sq_%s.txt" % {"cfg3": "cfg3", "north_star": "ns", "cfg3_dense": "cfg3_dense", "north_star_dense": "ns_dense", "cfg5": "cfg5"}.get(workload, "ns")
     paths = sorted(p for p in os.listdir(d) if p.endswith(suffix)) if os.path.isdir(d) else []
     if not paths:
         return None
@@ -384,7 +384,7 @@ def extra_legs(r, frame, work, steps):
     out = {}
     K = max(3, min(steps, 8))
 
-    def run(name, size, planes, describe, kernel_opt=0):
+    def run(name, size, planes, describe, kernel_opt=0, valu_key=None):
         fr = frame[:size * size]
         r.set_option("kernel", kernel_opt)
         with torch.cuda.stream(work):
@@ -394,6 +394,8 @@ def extra_legs(r, frame, work, steps):
         out[name] = {"workload": describe, "ms_per_frame": t / K * 1e3, "Msamples_per_s": float(size) * size * planes / (t / K) / 1e6,
                      "kernel": {1: "gather", 2: "slab-staged", 4: "column-stream"}.get(kernel, str(kernel)),
                      "roofline": roofline(r, kms, alg, size)}
+        if valu_key:   # (a leg bound by vector-instruction issue: its own SQ pass under profiles/)
+            out[name]["roofline_valu"] = roofline_valu(kms, valu_key)
 
     # cfg2: 256^3 u8 VGH, the reference's default deptex ramp (NV20VolRen3D.cpp:1479-1486), 512^2 x 256, no shading
     n = 256
@@ -500,7 +502,7 @@ def extra_legs(r, frame, work, steps):
     # a displacement of up to +-77 voxels at 512^3: the brick flags' reach covers the volume, every in-volume sample pays
     # its two noise lookups
     r.set_perturb(libc_noise_tex(32), (.2, .1, 0, 0), (.2, 2.1, 4.5, 8.7))
-    run("cfg5", 1024, 1024, "cfg5 as SURVEY 8(d) states it: noise-perturbed fetch, 32^3 noise, weights .2/.1, scales .2/2.1: gather kernel")
+    run("cfg5", 1024, 1024, "cfg5 as SURVEY 8(d) states it: noise-perturbed fetch, 32^3 noise, weights .2/.1, scales .2/2.1: gather kernel", valu_key="cfg5")
     # ... and the same at a tenth of the weights (round 2's leg: displacements of +-7.7 voxels, which the flags can bracket)
     r.set_perturb(libc_noise_tex(32), (.02, .01, 0, 0), (.2, 2.1, 4.5, 8.7))
     run("cfg5_tenth_of_the_weights", 1024, 1024, "cfg5 with weights .02/.01 (a tenth of the stated ones; NOT the configuration SURVEY 8(d) names): gather kernel")
