@@ -190,7 +190,7 @@ extern "C" void smk_destroy(smk_ctx *c) {
   if (c->tf_stream) { (void)hipStreamSynchronize(c->tf_stream); (void)hipStreamDestroy(c->tf_stream); }
   free_brick_set(c->br3);
   smk_cols_free(&c->cols);
-  void *ptrs[] = {c->d_shadow_barrier, c->d_tf_raw, c->d_tlut, c->d_tf_h, c->d_tf3d, c->d_tf3d_occ, c->d_noise, c->d_out, c->d_depth, c->d_light[0], c->d_light[1]};
+  void *ptrs[] = {c->d_light_hist, c->d_shadow_barrier, c->d_tf_raw, c->d_tlut, c->d_tf_h, c->d_tf3d, c->d_tf3d_occ, c->d_noise, c->d_out, c->d_depth, c->d_light[0], c->d_light[1]};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (c->slab.h_status) (void)hipHostFree(c->slab.h_status);
@@ -863,11 +863,11 @@ extern "C" int smk_get_shadowcoef(smk_ctx *c, smk_shadowcoef *out) {
 extern "C" int smk_get_light_buffer(smk_ctx *c, float *rgba_out, int *lb_out) {
   if (!c) return 1;
   HIPCHK(c, hipSetDevice(c->device));
-  if (!c->light_lb || !c->d_light[c->light_final]) FAIL(c, "smk_get_light_buffer: no frame with shadows has been rendered");
+  if (!c->light_lb || !c->d_light_last) FAIL(c, "smk_get_light_buffer: no frame with shadows has been rendered");
   if (lb_out) *lb_out = c->light_lb;
   if (rgba_out) {
     HIPCHK(c, hipDeviceSynchronize());
-    HIPCHK(c, hipMemcpy(rgba_out, c->d_light[c->light_final], (size_t)c->light_lb * c->light_lb * 16, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(rgba_out, c->d_light_last, (size_t)c->light_lb * c->light_lb * 16, hipMemcpyDeviceToHost));
   }
   return 0;
 }
@@ -1161,6 +1161,7 @@ extern "C" int smk_set_option(smk_ctx *c, const char *key, int value) {
   else if (!strcmp(key, "slab_sched")) c->opt_slab_sched = value < 0 ? 0 : (value > 15 ? 15 : value);
   else if (!strcmp(key, "slab_ns")) c->opt_slab_ns = value < 0 ? 0 : (value > 63 ? 63 : value);
   else if (!strcmp(key, "tile")) c->opt_tile = value;
+  else if (!strcmp(key, "shadow_march")) c->opt_shadow_march = value ? 1 : 0;  // (0: a launch per slice, the form of rounds 1-2)
   else if (!strcmp(key, "shadow_fused")) c->opt_lockstep = value ? (c->opt_lockstep | 256) : (c->opt_lockstep & ~256);  // (developer: all slices in one cooperative launch)
   else if (!strcmp(key, "slab_split")) c->slab.opt_split = value < 0 ? 0 : (value > 8 ? 8 : value);
   else if (!strcmp(key, "cols_shape")) c->opt_cols = (c->opt_cols & ~0xff) | (value & 0xff);
@@ -1719,6 +1720,33 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
     smk_shadowcoef sc;
     if (compute_shadowcoef(c, &sc)) return 1;
     const size_t nl = (size_t)sc.LB * sc.LB;
+    // The two marches (smk_shadow.hip) keep every slice's light buffer: (nslices + 1) buffers.  Where that does not fit
+    // (more than a quarter of the device's free memory, or 32 GB) the frame is a launch per slice, as with the option off.
+    const size_t nhist = nl * ((size_t)sc.nslices + 1);
+    bool march = c->opt_shadow_march && !(c->opt_lockstep & 256);
+    if (march && nhist > c->light_hist_cap) {
+      size_t fr = 0, tot = 0;
+      if (c->d_light_hist) (void)hipFree(c->d_light_hist);
+      c->d_light_hist = nullptr;
+      c->light_hist_cap = 0;
+      c->d_light_last = nullptr;
+      if (hipMemGetInfo(&fr, &tot) != hipSuccess || nhist * 16 > fr / 4 || nhist * 16 > ((size_t)32 << 30) ||
+          hipMalloc((void **)&c->d_light_hist, nhist * 16) != hipSuccess) {
+        (void)hipGetLastError();
+        c->d_light_hist = nullptr;
+        march = false;
+      } else c->light_hist_cap = nhist;
+    }
+    if (march) {
+      HIPCHK(c, hipEventRecord(c->ev0, s));
+      hipError_t e = smk_launch_shadow_march(P, sc, c->dtype, c->tf_mode, sk, c->d_light_hist, s);
+      if (e == hipErrorNotSupported) FAIL(c, "smk_render: no shadow kernel instance for this configuration");
+      HIPCHK(c, e);
+      HIPCHK(c, hipEventRecord(c->ev1, s));
+      c->d_light_last = c->d_light_hist + (size_t)sc.nslices * nl;
+      // the history is written once (16 B per texel and slice), the frame once
+      c->last_alg_bytes += (double)sc.nslices * (16.0 * (double)nl);
+    } else {
     if (nl > c->light_cap) {
       for (int k = 0; k < 2; ++k) {
         if (c->d_light[k]) (void)hipFree(c->d_light[k]);
@@ -1726,6 +1754,7 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
         HIPCHK(c, hipMalloc((void **)&c->d_light[k], nl * 16));
       }
       c->light_cap = nl;
+      c->d_light_last = nullptr;
     }
     HIPCHK(c, hipEventRecord(c->ev0, s));
     HIPCHK(c, hipMemsetAsync(c->d_light[0], 0, nl * 16, s));
@@ -1735,11 +1764,13 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
     if (e == hipErrorNotSupported) FAIL(c, "smk_render: no shadow kernel instance for this configuration");
     HIPCHK(c, e);
     HIPCHK(c, hipEventRecord(c->ev1, s));
+    c->d_light_last = c->d_light[sc.nslices & 1];
+    // per slice the frame buffer (read + write where the slice covers it) and both light buffers move again
+    c->last_alg_bytes += (double)sc.nslices * (32.0 * (double)nl);
+    }
     c->light_final = sc.nslices & 1;
     c->light_lb = sc.LB;
     c->last_kernel = 3;
-    // per slice the frame buffer (read + write where the slice covers it) and both light buffers move again
-    c->last_alg_bytes += (double)sc.nslices * (32.0 * (double)nl);
     if (c->tf_mode == 1 && c->tf_cur >= 0) {  // this frame read the current table version (refresh_tf2d waits for this before rewriting it)
       HIPCHK(c, hipEventRecord(c->tfv[c->tf_cur].used, s));
       c->tfv[c->tf_cur].used_valid = true;

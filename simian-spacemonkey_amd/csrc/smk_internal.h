@@ -258,6 +258,10 @@ struct smk_ctx {
   float4 *d_light[2] = {nullptr, nullptr};  // ping-pong light buffers, light_cap texels each
   size_t light_cap = 0;
   int light_final = 0, light_lb = 0;        // which one the last frame finished in, and its edge
+  float4 *d_light_hist = nullptr;           // [nslices + 1][LB][LB]: every slice's light buffer (the two marches, smk_shadow.hip)
+  size_t light_hist_cap = 0;                // texels
+  const float4 *d_light_last = nullptr;     // the light buffer the last frame with shadows left (in d_light[] or the history)
+  int opt_shadow_march = 1;                 // option "shadow_march": 1 = two marches (default), 0 = a launch per slice
   unsigned *d_shadow_barrier = nullptr;     // the fused shadow launch's grid-barrier counter
 
   // perturbation
@@ -311,6 +315,8 @@ hipError_t smk_launch_count_inside(const RenderParams &P, unsigned long long *d_
 // one launch per slice (smk_shadow.hip); L0 cleared by the caller
 hipError_t smk_launch_shadow(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, int shade_kind,
                              float4 *L0, float4 *L1, unsigned *barrier /* one device word for the fused launch's grid barrier, or null */, hipStream_t s);
+hipError_t smk_launch_shadow_march(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, int shade_kind,
+                                   float4 *hist, hipStream_t s);
 // returns hipErrorNotSupported (and *why) when the frame must use the gather kernel
 hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kind, int opt_T, int opt_tile, int forced,
                            const void *vox_native, const void *vox_xmajor, SlabAux *aux, const char **why,

@@ -294,6 +294,206 @@ __global__ __launch_bounds__(256) void smk_k_shadow_fused(const RenderParams P, 
   }
 }
 
+// ---- the two marches (round 3, the default).  A texel of the light buffer depends on ITSELF alone from slice to slice
+// (shadow_light_texel reads Lprev[o], writes Lnext[o]); only the eye pass reads the buffer at an arbitrary position.  So the
+// recurrence over slices is a ray-march per TEXEL along its light ray -- no launch boundary needed -- provided every slice's
+// light buffer is kept for the eye pass to look up: hist[k][LB][LB], k = 0..nslices (288 GB of HBM: 512 slices of a 512^2
+// buffer are 2.1 GB).  With the history in memory an eye pixel depends on itself alone, too: the eye pass is a ray-march per
+// PIXEL.  Two launches instead of nslices, the very same operations per sample in the very same order (the per-slice
+// functions above, with the running value in registers): frames and light buffers are bit-identical to the per-slice form.
+//
+// Conservative range of slices whose sample E + tau(k) D, tau(k) = fma(k, dnum, num0) / den, can lie inside the volume with
+// tau > 0: solved in real arithmetic on a box widened by 0.05 voxels, +- 2 slices; anything doubtful gives the whole range.
+// It only brackets: the exact per-sample tests of the per-slice form decide inside it.
+__device__ __forceinline__ void shadow_k_range(const RenderParams &P, float num0, float dnum, float den, const float D[3],
+                                               const float E[3], int n, int &k0, int &k1) {
+  k0 = 1;
+  k1 = n;
+  float ta = 0.0f, tb = __int_as_float(0x7f800000);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float lo = -0.55f, hi = (float)P.N[a] - 0.45f;
+    if (fabsf(D[a]) > 1e-20f) {
+      const float inv = 1.0f / D[a];
+      const float t1 = (lo - E[a]) * inv, t2 = (hi - E[a]) * inv;
+      ta = fmaxf(ta, fminf(t1, t2));
+      tb = fminf(tb, fmaxf(t1, t2));
+    } else if (!(E[a] >= lo && E[a] <= hi)) {
+      k1 = 0;  // never inside
+      return;
+    }
+  }
+  if (!(ta <= tb)) {  // (NaN included: but then nothing passes the per-sample test either... keep the whole range for NaN)
+    if (ta > tb) k1 = 0;
+    return;
+  }
+  const float mg = 1e-4f * (fabsf(ta) + (isinf(tb) ? 0.0f : fabsf(tb))) + 1e-30f;
+  ta -= mg;
+  tb += mg;
+  if (!(fabsf(dnum) > 0.0f) || !(fabsf(den) > 0.0f) || isinf(den) || isinf(dnum)) return;
+  // k = (tau den - num0) / dnum
+  const float ka = (ta * den - num0) / dnum;
+  const float kb = isinf(tb) ? ((den / dnum) > 0.0f ? __int_as_float(0x7f800000) : -__int_as_float(0x7f800000)) : (tb * den - num0) / dnum;
+  if (ka != ka || kb != kb) return;
+  const float klo = fminf(ka, kb) - 2.0f, khi = fmaxf(ka, kb) + 2.0f;
+  if (klo > (float)n || khi < 1.0f) {
+    k1 = 0;
+    return;
+  }
+  k0 = max(1, (int)floorf(fmaxf(klo, 1.0f)));
+  k1 = min(n, (int)ceilf(fminf(khi, (float)n)));
+}
+
+// blocks -> 16x16 tiles, XCD-aware: block b runs on XCD b % 8, which takes a contiguous run of the tiles
+__device__ __forceinline__ bool shadow_tile_of_block(int bid, int ntiles, int &tile) {
+  const int per = (ntiles + 7) >> 3;
+  const int k = bid >> 3;
+  tile = (bid & 7) * per + k;
+  return k < per && tile < ntiles;
+}
+
+// the light march: one thread per texel, every slice; hist[k] = the light buffer after slices 1..k (hist[0] = cleared)
+template <int DT, int TF>
+__global__ __launch_bounds__(256) void smk_k_shadow_light_march(const RenderParams P, const ShadowSlice Q, float4 *hist) {
+  const smk_shadowcoef &sc = Q.sc;
+  int tile;
+  if (!shadow_tile_of_block((int)blockIdx.x, Q.light_bx * Q.light_bx, tile)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = (tile % Q.light_bx) * 16 + (wave & 1) * 8 + (lane & 7), y = (tile / Q.light_bx) * 16 + (wave >> 1) * 8 + (lane >> 3);
+  if (x >= sc.LB || y >= sc.LB) return;
+  const size_t nl = (size_t)sc.LB * sc.LB, o = (size_t)y * sc.LB + x;
+  const float a = __fmaf_rn((float)x + 0.5f, sc.las, sc.lal), bb = __fmaf_rn((float)y + 0.5f, sc.las, sc.lal);
+  const float nG = __fmaf_rn(a, sc.nGx, __fmaf_rn(bb, sc.nGy, sc.nGc));
+  float G[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) G[q] = __fmaf_rn(a, sc.Gx[q], __fmaf_rn(bb, sc.Gy[q], sc.Gc[q]));
+  int k0, k1;
+  shadow_k_range(P, sc.lnum0, sc.ldnum, nG, G, sc.Lc, sc.nslices, k0, k1);
+  float4 L = make_float4(0.f, 0.f, 0.f, 0.f);
+  hist[o] = L;
+  for (int k = 1; k <= sc.nslices; ++k) {
+    if (k >= k0 && k <= k1) {
+      const float w = __fdiv_rn(__fmaf_rn((float)k, sc.ldnum, sc.lnum0), nG);
+      bool in = w > 0.0f && !isinf(w);
+      float p[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        p[q] = __fmaf_rn(w, G[q], sc.Lc[q]);
+        in = in && p[q] >= -0.5f && p[q] <= (float)P.N[q] - 0.5f;
+      }
+      if (in && !shadow_brick_empty(P, p[0], p[1], p[2])) {
+        float ch0, ch1, ch2, ch3, n0, n1, n2;
+        shadow_fetch<DT, TF, false>(P, p[0], p[1], p[2], ch0, ch1, ch2, ch3, n0, n1, n2);
+        float4 col;
+        if (shadow_maybe_visible<TF>(P, ch0, ch1) && smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col)) {
+          const float al = col.w;  // (R8kVolRen3D.cpp:3150-3165, as shadow_light_texel)
+          L.x = smk_sat(__fmaf_rn(al, smk_sat(col.x) - L.x, L.x));
+          L.y = smk_sat(__fmaf_rn(al, smk_sat(col.y) - L.y, L.y));
+          L.z = smk_sat(__fmaf_rn(al, smk_sat(col.z) - L.z, L.z));
+          L.w = smk_sat(__fmaf_rn(1.0f - al, L.w, al));
+        }
+      }
+    }
+    hist[(size_t)k * nl + o] = L;
+  }
+}
+
+// the eye march: one thread per pixel, the slices in the order of the per-slice launches (away from the light), the frame
+// value in registers; slice k is shaded under hist[k - 1]
+template <int DT, int TF, int SH>
+__global__ __launch_bounds__(256) void smk_k_shadow_eye_march(const RenderParams P, const ShadowSlice Q, const float4 *hist) {
+  const smk_shadowcoef &sc = Q.sc;
+  int tile;
+  if (!shadow_tile_of_block((int)blockIdx.x, Q.eye_blocks, tile)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = (tile % Q.eye_bx) * 16 + (wave & 1) * 8 + (lane & 7), j = (tile / Q.eye_bx) * 16 + (wave >> 1) * 8 + (lane >> 3);
+  const bool live = i < P.W && j < P.H;
+  const float px = __fmaf_rn((float)i + 0.5f, sc.pxs, sc.pxl), py = __fmaf_rn((float)j + 0.5f, sc.pys, sc.pyl);
+  const float nD = __fmaf_rn(px, sc.nDx, __fmaf_rn(py, sc.nDy, sc.nDc));
+  float D[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) D[a] = __fmaf_rn(px, sc.Dx[a], __fmaf_rn(py, sc.Dy[a], sc.Dc[a]));
+  int k0, k1;
+  shadow_k_range(P, sc.num0, sc.dnum, nD, D, sc.Ec, sc.nslices, k0, k1);
+  if (!live) k1 = 0;
+  // the wave walks the slices together (its 64 samples of a slice lie in one thin slab of the volume)
+  int klo = k1 >= k0 ? k0 : 0x7fffffff, khi = k1 >= k0 ? k1 : -0x7fffffff;
+  for (int off = 32; off > 0; off >>= 1) {
+    klo = min(klo, __shfl_xor(klo, off));
+    khi = max(khi, __shfl_xor(khi, off));
+  }
+  const size_t nl = (size_t)sc.LB * sc.LB;
+  float4 C = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = klo; k <= khi; ++k) {
+    if (!__any(k <= k1)) break;  // every ray of the wave is past its range or saturated
+    if (k < k0 || k > k1) continue;
+    const float tau = __fdiv_rn(__fmaf_rn((float)k, sc.dnum, sc.num0), nD);
+    if (!(tau > 0.0f) || isinf(tau)) continue;
+    float p[3];
+    bool in = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      p[a] = __fmaf_rn(tau, D[a], sc.Ec[a]);
+      in = in && p[a] >= -0.5f && p[a] <= (float)P.N[a] - 0.5f;
+    }
+    if (!in) continue;
+    if (shadow_brick_empty(P, p[0], p[1], p[2])) continue;
+    float ch0, ch1, ch2, ch3, n0 = 0.f, n1 = 0.f, n2 = 0.f;
+    shadow_fetch<DT, TF, SH != 0>(P, p[0], p[1], p[2], ch0, ch1, ch2, ch3, n0, n1, n2);
+    float4 col;
+    if (!shadow_maybe_visible<TF>(P, ch0, ch1)) continue;
+    if (!smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col)) continue;
+    const float lw = __fmaf_rn(p[0], sc.Wm[0], __fmaf_rn(p[1], sc.Wm[1], __fmaf_rn(p[2], sc.Wm[2], sc.Wm[3])));
+    const float lxx = __fmaf_rn(p[0], sc.Xm[0], __fmaf_rn(p[1], sc.Xm[1], __fmaf_rn(p[2], sc.Xm[2], sc.Xm[3])));
+    const float lyy = __fmaf_rn(p[0], sc.Ym[0], __fmaf_rn(p[1], sc.Ym[1], __fmaf_rn(p[2], sc.Ym[2], sc.Ym[3])));
+    float shadow[3];
+    shadow_lookup<false>(hist + (size_t)(k - 1) * nl, sc.LB, __fmaf_rn(__fdiv_rn(lxx, lw), sc.lscale, sc.lbias),
+                         __fmaf_rn(__fdiv_rn(lyy, lw), sc.lscale, sc.lbias), shadow);
+    const float4 src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1, shadow);
+    if (sc.front_to_back) {
+      const float w = 1.0f - C.w;
+      C.x = __fmaf_rn(w, src.x, C.x);
+      C.y = __fmaf_rn(w, src.y, C.y);
+      C.z = __fmaf_rn(w, src.z, C.z);
+      C.w = __fmaf_rn(w, src.w, C.w);
+      if (C.w == 1.0f) k1 = k;  // exact: every later weight (1-A) is 0 (the per-slice form leaves such a pixel alone)
+    } else {
+      const float w = 1.0f - src.w;
+      C.x = __fmaf_rn(w, C.x, src.x);
+      C.y = __fmaf_rn(w, C.y, src.y);
+      C.z = __fmaf_rn(w, C.z, src.z);
+      C.w = __fmaf_rn(w, C.w, src.w);
+    }
+  }
+  if (live) P.out[(size_t)j * P.W + i] = C;
+}
+
+template <int DT, int TF, int SH>
+static hipError_t run_march(const RenderParams &P, ShadowSlice Q, float4 *hist, hipStream_t s) {
+  const smk_shadowcoef &sc = Q.sc;
+  Q.eye_bx = (P.W + 15) / 16;
+  Q.eye_blocks = Q.eye_bx * ((P.H + 15) / 16);
+  Q.light_bx = (sc.LB + 15) / 16;
+  const int lblocks = 8 * ((Q.light_bx * Q.light_bx + 7) / 8), eblocks = 8 * ((Q.eye_blocks + 7) / 8);
+  hipLaunchKernelGGL((smk_k_shadow_light_march<DT, TF>), dim3(lblocks), dim3(256), 0, s, P, Q, hist);
+  hipLaunchKernelGGL((smk_k_shadow_eye_march<DT, TF, SH>), dim3(eblocks), dim3(256), 0, s, P, Q, (const float4 *)hist);
+  return hipGetLastError();
+}
+
+// hist: [nslices + 1][LB][LB] texels; the light buffer the frame leaves is hist[nslices]
+hipError_t smk_launch_shadow_march(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, int shade_kind,
+                                   float4 *hist, hipStream_t s) {
+  ShadowSlice Q;
+  memset(&Q, 0, sizeof Q);
+  Q.sc = sc;
+#define CASE(D, T, S) \
+  if (dtype == D && tf_mode == T && shade_kind == S) return run_march<D, T, S>(P, Q, hist, s);
+  CASE(0, 1, 0) CASE(0, 1, 1) CASE(0, 2, 0) CASE(0, 2, 1)
+  CASE(1, 1, 0) CASE(1, 1, 1) CASE(1, 2, 0) CASE(1, 2, 1)
+#undef CASE
+  return hipErrorNotSupported;
+}
+
 template <int DT, int TF, int SH>
 static hipError_t run(const RenderParams &P, ShadowSlice Q, float4 *L0, float4 *L1, unsigned *barrier, hipStream_t s) {
   const smk_shadowcoef &sc = Q.sc;

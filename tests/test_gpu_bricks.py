@@ -114,9 +114,10 @@ def test_ragged_and_thin(R):
         assert np.array_equal(s0, g) and np.array_equal(s1, g), (dims, pose)
 
 
-def test_depth_and_clip_plane_frames_on_the_gather_kernel(R):
-    """a frame only the gather kernel renders (first-hit depth requested, here with a free clip plane): flags on == flags
-    off, depth included"""
+def test_depth_and_clip_plane_frames_on_both_kernels(R):
+    """first-hit depth requested, with a free clip plane (since round 3 the slice-ring kernel renders such frames too):
+    flags on == flags off, depth included, on the gather kernel and on the slice-ring kernel, and the two kernels agree
+    bit for bit"""
     sc = make_scene("cfg3", n=64, size=96, steps=128, pose="rot", f32=True, shade=1)
     n = np.array([0.35, -0.2, -0.9])
     n /= np.linalg.norm(n)
@@ -124,18 +125,24 @@ def test_depth_and_clip_plane_frames_on_the_gather_kernel(R):
     centre = mv @ np.array([float(sc.fsize[0]) / 2, float(sc.fsize[1]) / 2, float(sc.fsize[2]) / 2, 1.0])
     sc.clip_plane = (n[0], n[1], n[2], -float(n @ centre[:3]) + 0.03)   # through (almost) the volume's middle
     out = {}
-    for b in (0, 1):
-        R.set_option("bricks", b)
+    try:
+        for kern in (1, 2):
+            for b in (0, 1):
+                R.set_option("bricks", b)
+                push_scene(R, sc)
+                R.set_option("kernel", kern)
+                out[kern, b] = R.render(depth=True)
+                assert R.last_frame_info()[0] == kern
+            assert np.array_equal(out[kern, 0][0], out[kern, 1][0])
+            assert np.array_equal(out[kern, 0][1], out[kern, 1][1])
+        assert np.array_equal(out[1, 1][0], out[2, 1][0])
+        assert np.array_equal(out[1, 1][1], out[2, 1][1])
+        assert out[1, 0][0][..., 3].max() > 0.05
+    finally:
+        sc.clip_plane = None
         push_scene(R, sc)
+        R.set_option("bricks", 1)
         R.set_option("kernel", 0)
-        out[b] = R.render(depth=True)
-        assert R.last_frame_info()[0] == 1
-    assert np.array_equal(out[0][0], out[1][0])
-    assert np.array_equal(out[0][1], out[1][1])
-    assert out[0][0][..., 3].max() > 0.05
-    sc.clip_plane = None
-    push_scene(R, sc)
-    R.set_option("bricks", 1)
 
 
 @pytest.mark.parametrize("f32", [False, True])

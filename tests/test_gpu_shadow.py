@@ -144,3 +144,28 @@ def test_all_slices_in_one_cooperative_launch(R):
         R.set_option("shadow_fused", 0)
     assert R.last_frame_info()[0] == 3
     assert np.array_equal(a, b) and np.array_equal(la, lb)
+
+
+@pytest.mark.parametrize("light", sorted(LIGHTS))
+@pytest.mark.parametrize("kind,f32,shade,pose", [("cfg3", True, 1, "rot"), ("cfg3", False, 1, "diag"), ("tf3d", False, 0, "back"),
+                                                 ("cfg4", True, 1, "side")])
+def test_two_marches_equal_a_launch_per_slice(R, light, kind, f32, shade, pose):
+    """The default since round 3: one march per light-buffer texel (its value depends on itself alone from slice to slice)
+    that keeps every slice's light buffer, then one march per eye pixel that looks slice k's shading up in buffer k - 1 --
+    two launches instead of one per slice, the same operations in the same order: frame and light buffer bit-identical to
+    the per-slice launches (option shadow_march 0), for lights on either side of the viewer (both blend orders)."""
+    sc = make_scene(kind, n=48, size=112, steps=150, f32=f32, shade=shade, pose=pose)
+    sc.light_pos = LIGHTS[light]
+    sc.shadow = (96, 0.7)
+    push_scene(R, sc)
+    a = R.render()
+    la = R.light_buffer()
+    assert R.last_frame_info()[0] == 3
+    R.set_option("shadow_march", 0)
+    try:
+        b = R.render()
+        lb = R.light_buffer()
+    finally:
+        R.set_option("shadow_march", 1)
+    assert a[..., 3].max() > 0.05 and la[..., 3].max() > 0.05, "vacuous scene"
+    assert np.array_equal(a, b) and np.array_equal(la, lb)
