@@ -736,7 +736,16 @@ int orc_render_shadow(const orc_volume *v, const orc_classify *tf, const orc_cam
   if (nthreads <= 0) nthreads = omp_get_max_threads();
 #endif
   for (int k = 1; k <= sc->nslices; ++k) {
-    const float num = fmaf((float)k, sc->dnum, sc->num0), lnum = fmaf((float)k, sc->ldnum, sc->lnum0);
+    const float lnum = fmaf((float)k, sc->ldnum, sc->lnum0);
+    /* The eye sample of slice k is plane m of the pixel's ray, planes counted FROM THE EYE (m = k - 1 when the slices run away
+     * from the viewer, nslices - k when they run towards it): with D_a = fma(px, Dx_a, fma(py, Dy_a, Dc_a)),
+     * nD = fma(px, nDx, fma(py, nDy, nDc)), numA = the numerator of plane 0 (fma(1, dnum, num0) or fma(nslices, dnum, num0)),
+     * dB = +-dnum:  tauA = numA / nD, dtau = dB / nD, A_a = fma(tauA, D_a, Ec_a), B_a = dtau * D_a, sample = fma(m, B, A),
+     * which exists where fma(m, dtau, tauA) is positive and finite.  (Round 3: the product's ray-marchers render the eye
+     * pass as one march per pixel over these planes; the chain is theirs -- smk_ray_AB, smk_device.h.) */
+    const float numA = sc->front_to_back ? fmaf(1.0f, sc->dnum, sc->num0) : fmaf((float)sc->nslices, sc->dnum, sc->num0);
+    const float dB = sc->front_to_back ? sc->dnum : -sc->dnum;
+    const int m = sc->front_to_back ? k - 1 : sc->nslices - k;
     /* ---- eye pass: reads L0 (the buffer as the previous slices left it) */
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
@@ -745,14 +754,18 @@ int orc_render_shadow(const orc_volume *v, const orc_classify *tf, const orc_cam
       for (int i = 0; i < W; ++i) {
         const float px = fmaf((float)i + 0.5f, sc->pxs, sc->pxl), py = fmaf((float)j + 0.5f, sc->pys, sc->pyl);
         const float nD = fmaf(px, sc->nDx, fmaf(py, sc->nDy, sc->nDc));
-        const float tau = num / nD;
-        if (!(tau > 0.0f) || isinf(tau)) continue;
+        const float tauA = numA / nD, dtau = dB / nD;
+        if (!(fabsf(nD) > 0.0f) || !(fabsf(tauA) < INFINITY) || !(fabsf(dtau) < INFINITY)) continue;
+        const float tau = fmaf((float)m, dtau, tauA);
+        if (!(tau > 0.0f) || !(tau < INFINITY)) continue;
         float p[3];
         int in = 1;
         for (int a = 0; a < 3; ++a) {
           const float D = fmaf(px, sc->Dx[a], fmaf(py, sc->Dy[a], sc->Dc[a]));
-          p[a] = fmaf(tau, D, sc->Ec[a]);
-          if (!(p[a] >= -0.5f && p[a] <= (float)N[a] - 0.5f)) in = 0;
+          const float A = fmaf(tauA, D, sc->Ec[a]), B = dtau * D;
+          p[a] = fmaf((float)m, B, A);
+          /* (the box 2^-10 voxels wide: the last slice lies ON the far corner / face, where the chain's rounding would decide) */
+          if (!(p[a] >= -0.5f - 0.0009765625f && p[a] <= (float)N[a] - 0.5f + 0.0009765625f)) in = 0;
         }
         if (!in) continue;
         float *C = rgba + 4 * ((size_t)j * W + i);

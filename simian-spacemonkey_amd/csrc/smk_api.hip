@@ -1709,21 +1709,56 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
   c->slab.status_slot = (int)(c->frame_id % SMK_STATUS_RING);
   c->slab.status_tag = c->cols.status_tag = (int)((c->frame_id & 0x7fffff) << 8);
   if (c->slab.h_status) ((volatile int *)c->slab.h_status)[c->slab.status_slot] = 0;
+  bool ev0_recorded = false;  // (frames with shadows open the kernel-time bracket before their light march)
   if (c->shadow_on) {
-    // ---- half-angle slicing: S launches, each the eye pass and the light pass of one slice (smk_shadow.hip)
+    // ---- half-angle slicing (smk_shadow.hip): the light march, then the eye pass as an ordinary frame of the ray-marchers
+    // below over the half-angle slices (SmkShadowRays) -- or, option shadow_march 0, a launch per slice
     const int sk = shade_kind_of(c);
     if (c->tf_mode == 0) FAIL(c, "smk_render: shadows need a 2-D or 3-D transfer function (the 1-D table renderer has no shadow mode)");
     if (sk == 2) FAIL(c, "smk_render: shadows are implemented for R8k shading or none (NV20 combiners: no shadow mode in NV20VolRen3D)");
     if (c->nranks > 1) FAIL(c, "smk_render: shadows need the whole volume on one GPU (the light buffer couples every slice of every brick)");
     if (P.pert_on || c->cplane_on || c->clip_axis || d_depth)
       FAIL(c, "smk_render: shadows cannot be combined with perturbation, clip planes or depth output");
+    if (c->opt_kernel == 3) FAIL(c, "smk_render: the column-stream kernel has no shadow mode");
     smk_shadowcoef sc;
     if (compute_shadowcoef(c, &sc)) return 1;
+    // the eye rays over the half-angle slices, planes counted from the eye (smk_internal.h SmkShadowRays)
+    SmkShadowRays &h = P.sh;
+    memset(&h, 0, sizeof h);
+    h.on = 1;
+    for (int a = 0; a < 3; ++a) { h.Ec[a] = sc.Ec[a]; h.Dc[a] = sc.Dc[a]; h.Dx[a] = sc.Dx[a]; h.Dy[a] = sc.Dy[a]; }
+    h.nDc = sc.nDc; h.nDx = sc.nDx; h.nDy = sc.nDy;
+    if (sc.front_to_back) { h.numA = fmaf(1.0f, sc.dnum, sc.num0); h.dB = sc.dnum; h.k0 = 1; h.dk = 1; }
+    else { h.numA = fmaf((float)sc.nslices, sc.dnum, sc.num0); h.dB = -sc.dnum; h.k0 = sc.nslices; h.dk = -1; }
+    h.LB = sc.LB;
+    for (int q = 0; q < 4; ++q) { h.Xm[q] = sc.Xm[q]; h.Ym[q] = sc.Ym[q]; h.Wm[q] = sc.Wm[q]; }
+    h.lscale = sc.lscale; h.lbias = sc.lbias;
+    {
+      smk_raycoef &rc = P.rc;
+      memset(&rc, 0, sizeof rc);
+      rc.pxs = sc.pxs; rc.pxl = sc.pxl; rc.pys = sc.pys; rc.pyl = sc.pyl;
+      rc.nplanes = sc.nslices;
+      // (Bc: the central ray's step, which the kernel choice below keys its measurements on)
+      const double nDc = (double)sc.nDc != 0.0 ? (double)sc.nDc : 1.0;
+      for (int a = 0; a < 3; ++a) rc.Bc[a] = (float)((double)h.dB / nDc * (double)sc.Dc[a]);
+    }
+    // The last slice lies ON the volume's far corner -- on a whole face when the half-way vector is a volume axis (a light at
+    // the eye) -- where a sample's coordinate, the end of an fma chain, lands on either side of the face by rounding.  The
+    // reference draws that slice (a polygon clipped against the box keeps its boundary); the eye pass's membership test is
+    // therefore 2^-10 voxels wide of the box (clamp-to-edge fetches: the value at the face).  The CPU checker does the same.
+    for (int a = 0; a < 3; ++a) {
+      P.lo[a] = -0.5f - SMK_SHADOW_BOX_EPS;
+      P.hi[a] = (float)c->N[a] - 0.5f + SMK_SHADOW_BOX_EPS;
+      P.hin[a] = P.hi[a];
+      P.top[a] = 1;
+    }
+    P.blend = SMK_BLEND_FRONT_TO_BACK;  // (a light that faces the viewer: the per-slice form blends back to front, the marchers
+                                        //  composite the same samples front to back -- the association of the blend differs)
     const size_t nl = (size_t)sc.LB * sc.LB;
-    // The two marches (smk_shadow.hip) keep every slice's light buffer: (nslices + 1) buffers.  Where that does not fit
-    // (more than a quarter of the device's free memory, or 32 GB) the frame is a launch per slice, as with the option off.
+    // The light march keeps every slice's light buffer: (nslices + 1) buffers.  Where that does not fit (more than a quarter
+    // of the device's free memory, or 32 GB) the frame is a launch per slice, as with the option off.
     const size_t nhist = nl * ((size_t)sc.nslices + 1);
-    bool march = c->opt_shadow_march && !(c->opt_lockstep & 256);
+    bool march = c->opt_shadow_march && !(c->opt_lockstep & 256) && sc.nslices > 0;
     if (march && nhist > c->light_hist_cap) {
       size_t fr = 0, tot = 0;
       if (c->d_light_hist) (void)hipFree(c->d_light_hist);
@@ -1737,46 +1772,47 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
         march = false;
       } else c->light_hist_cap = nhist;
     }
+    c->light_lb = sc.LB;
     if (march) {
       HIPCHK(c, hipEventRecord(c->ev0, s));
-      hipError_t e = smk_launch_shadow_march(P, sc, c->dtype, c->tf_mode, sk, c->d_light_hist, s);
+      ev0_recorded = true;
+      hipError_t e = smk_launch_shadow_march(P, sc, c->dtype, c->tf_mode, c->d_light_hist, s);
+      if (e == hipErrorNotSupported) FAIL(c, "smk_render: no shadow kernel instance for this configuration");
+      HIPCHK(c, e);
+      h.hist = c->d_light_hist;
+      c->d_light_last = c->d_light_hist + (size_t)sc.nslices * nl;
+      // the history is written once (16 B per texel and slice)
+      c->last_alg_bytes += (double)sc.nslices * (16.0 * (double)nl);
+      // ... and the eye pass is the frame the code below renders
+    } else {
+      if (nl > c->light_cap) {
+        for (int k = 0; k < 2; ++k) {
+          if (c->d_light[k]) (void)hipFree(c->d_light[k]);
+          c->d_light[k] = nullptr;
+          HIPCHK(c, hipMalloc((void **)&c->d_light[k], nl * 16));
+        }
+        c->light_cap = nl;
+        c->d_light_last = nullptr;
+      }
+      HIPCHK(c, hipEventRecord(c->ev0, s));
+      HIPCHK(c, hipMemsetAsync(c->d_light[0], 0, nl * 16, s));
+      HIPCHK(c, hipMemsetAsync(d_rgba, 0, (size_t)c->W * c->H * 16, s));
+      if (!c->d_shadow_barrier) HIPCHK(c, hipMalloc((void **)&c->d_shadow_barrier, 16 * 9 * 4));  // (the common word + one per XCD, a cache line apart)
+      hipError_t e = smk_launch_shadow(P, sc, c->dtype, c->tf_mode, sk, c->d_light[0], c->d_light[1], c->d_shadow_barrier, s);
       if (e == hipErrorNotSupported) FAIL(c, "smk_render: no shadow kernel instance for this configuration");
       HIPCHK(c, e);
       HIPCHK(c, hipEventRecord(c->ev1, s));
-      c->d_light_last = c->d_light_hist + (size_t)sc.nslices * nl;
-      // the history is written once (16 B per texel and slice), the frame once
-      c->last_alg_bytes += (double)sc.nslices * (16.0 * (double)nl);
-    } else {
-    if (nl > c->light_cap) {
-      for (int k = 0; k < 2; ++k) {
-        if (c->d_light[k]) (void)hipFree(c->d_light[k]);
-        c->d_light[k] = nullptr;
-        HIPCHK(c, hipMalloc((void **)&c->d_light[k], nl * 16));
+      c->d_light_last = c->d_light[sc.nslices & 1];
+      // per slice the frame buffer (read + write where the slice covers it) and both light buffers move again
+      c->last_alg_bytes += (double)sc.nslices * (32.0 * (double)nl);
+      c->last_kernel = 3;
+      if (c->tf_mode == 1 && c->tf_cur >= 0) {  // this frame read the current table version (refresh_tf2d waits for this before rewriting it)
+        HIPCHK(c, hipEventRecord(c->tfv[c->tf_cur].used, s));
+        c->tfv[c->tf_cur].used_valid = true;
       }
-      c->light_cap = nl;
-      c->d_light_last = nullptr;
+      c->tcount++;
+      return 0;
     }
-    HIPCHK(c, hipEventRecord(c->ev0, s));
-    HIPCHK(c, hipMemsetAsync(c->d_light[0], 0, nl * 16, s));
-    HIPCHK(c, hipMemsetAsync(d_rgba, 0, (size_t)c->W * c->H * 16, s));
-    if (!c->d_shadow_barrier) HIPCHK(c, hipMalloc((void **)&c->d_shadow_barrier, 16 * 9 * 4));  // (the common word + one per XCD, a cache line apart)
-    hipError_t e = smk_launch_shadow(P, sc, c->dtype, c->tf_mode, sk, c->d_light[0], c->d_light[1], c->d_shadow_barrier, s);
-    if (e == hipErrorNotSupported) FAIL(c, "smk_render: no shadow kernel instance for this configuration");
-    HIPCHK(c, e);
-    HIPCHK(c, hipEventRecord(c->ev1, s));
-    c->d_light_last = c->d_light[sc.nslices & 1];
-    // per slice the frame buffer (read + write where the slice covers it) and both light buffers move again
-    c->last_alg_bytes += (double)sc.nslices * (32.0 * (double)nl);
-    }
-    c->light_final = sc.nslices & 1;
-    c->light_lb = sc.LB;
-    c->last_kernel = 3;
-    if (c->tf_mode == 1 && c->tf_cur >= 0) {  // this frame read the current table version (refresh_tf2d waits for this before rewriting it)
-      HIPCHK(c, hipEventRecord(c->tfv[c->tf_cur].used, s));
-      c->tfv[c->tf_cur].used_valid = true;
-    }
-    c->tcount++;
-    return 0;
   }
   // ---- auto mode: which kernel for this configuration?
   bool try_slab = c->opt_kernel != 1;
@@ -1792,7 +1828,8 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
                                     (unsigned long long)P.third_axis, (unsigned long long)(as * 2 + (P.rc.Bc[as] > 0)),
                                     (unsigned long long)c->sv, (unsigned long long)c->sg, (unsigned long long)(d_depth != nullptr),
                                     (unsigned long long)P.pert_on, (unsigned long long)c->tf_mode, (unsigned long long)c->s3v,
-                                    (unsigned long long)c->s3g, (unsigned long long)c->s3h, (unsigned long long)c->blend};
+                                    (unsigned long long)c->s3g, (unsigned long long)c->s3h, (unsigned long long)c->blend,
+                                    (unsigned long long)P.sh.on};
     sig = 1469598103934665603ull;
     for (unsigned long long v : f) sig = (sig ^ v) * 1099511628211ull;
     auto it = c->tune_choice.find(sig);
@@ -1860,7 +1897,7 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
     if (c->opt_lockstep & 16) HIPCHK(c, hipMemsetAsync(c->slab.d_diag, 0, 16 * sizeof(float), s));
     const char *why = nullptr;
     const int forced = c->opt_kernel == 2;
-    c->slab.frame_ev0 = c->ev0;
+    c->slab.frame_ev0 = ev0_recorded ? nullptr : c->ev0;
     const int knobs = c->opt_slab_T | (c->opt_slab_fly << 8) | (c->opt_slab_ns << 16) | (c->opt_slab_sched << 24);
     hipError_t e = smk_launch_slab(P, c->dtype, c->tf_mode, shade_kind_of(c), knobs, c->opt_tile, forced, c->d_vox, c->d_vox_x, &c->slab, &why, s);
     if (e == hipErrorNotSupported && why && !strcmp(why, "x-major copy unavailable")) {
@@ -1888,7 +1925,7 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
     FAIL(c, "smk_render: slab kernel forced but classification mode %d is gather-only", c->tf_mode);
   }
   if (c->last_kernel == 1) {
-    HIPCHK(c, hipEventRecord(c->ev0, s));
+    if (!ev0_recorded) HIPCHK(c, hipEventRecord(c->ev0, s));
     HIPCHK(c, smk_launch_gather(P, c->dtype, c->tf_mode, shade_kind_of(c), s));
   }
   HIPCHK(c, hipEventRecord(c->ev1, s));

@@ -276,6 +276,71 @@ __device__ __forceinline__ float smk_nrm(uint32_t a, uint32_t b, uint32_t c, uin
   return __fmaf_rn(v, 2.0f * SMK_INV255, -1.0f);
 }
 
+// ---- a pixel's ray: the voxel coordinate of plane m on axis a is fma(m, B_a, A_a).  View-aligned planes: A and B are
+// affine in the pixel coordinate (smk_raycoef).  Frames with shadows (SmkShadowRays, smk_internal.h): the planes are the
+// half-angle slices, the coefficients carry a division by the ray's component along the slice normal; `tauA`, `dtau` give
+// the ray parameter fma(m, dtau, tauA) of plane m, which must be positive and finite for the sample to exist (smk_tau_ok).
+// Returns false for a ray that runs parallel to the slices (no sample at all).
+__device__ __forceinline__ bool smk_ray_AB(const RenderParams &P, float px, float py, float A[3], float B[3], float &tauA, float &dtau) {
+  if (!P.sh.on) {
+    const smk_raycoef &rc = P.rc;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      A[a] = __fmaf_rn(px, rc.Ax[a], __fmaf_rn(py, rc.Ay[a], rc.Ac[a]));
+      B[a] = __fmaf_rn(px, rc.Bx[a], __fmaf_rn(py, rc.By[a], rc.Bc[a]));
+    }
+    tauA = 1.0f;
+    dtau = 0.0f;
+    return true;
+  }
+  const SmkShadowRays &sh = P.sh;
+  const float nD = __fmaf_rn(px, sh.nDx, __fmaf_rn(py, sh.nDy, sh.nDc));
+  tauA = __fdiv_rn(sh.numA, nD);
+  dtau = __fdiv_rn(sh.dB, nD);
+  const bool ok = fabsf(nD) > 0.0f && fabsf(tauA) < __int_as_float(0x7f800000) && fabsf(dtau) < __int_as_float(0x7f800000);
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float D = __fmaf_rn(px, sh.Dx[a], __fmaf_rn(py, sh.Dy[a], sh.Dc[a]));
+    A[a] = ok ? __fmaf_rn(tauA, D, sh.Ec[a]) : 0.0f;
+    B[a] = ok ? dtau * D : 0.0f;
+  }
+  if (!ok) { tauA = -1.0f; dtau = 0.0f; }
+  return ok;
+}
+__device__ __forceinline__ bool smk_tau_ok(float tauA, float dtau, int m) {
+  const float t = __fmaf_rn((float)m, dtau, tauA);
+  return t > 0.0f && t < __int_as_float(0x7f800000);
+}
+
+// bilinear lookup of a light buffer; texels outside it are 0 (the rest of the pbuffer stays cleared)
+__device__ __forceinline__ void smk_light_lookup(const float4 *L, int LB, float lx, float ly, float out[3]) {
+  const float fx0 = floorf(lx - 0.5f), fy0 = floorf(ly - 0.5f);
+  const float fx = (lx - 0.5f) - fx0, fy = (ly - 0.5f) - fy0;
+  out[0] = out[1] = out[2] = 0.0f;
+  if (!(fx0 >= -1.0f && fx0 < (float)LB && fy0 >= -1.0f && fy0 < (float)LB)) return;  // (also NaN)
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  float4 t[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int x = x0 + (q & 1), y = y0 + (q >> 1);
+    t[q] = (x >= 0 && x < LB && y >= 0 && y < LB) ? L[(size_t)y * LB + x] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  out[0] = smk_lerp(smk_lerp(t[0].x, t[1].x, fx), smk_lerp(t[2].x, t[3].x, fx), fy);
+  out[1] = smk_lerp(smk_lerp(t[0].y, t[1].y, fx), smk_lerp(t[2].y, t[3].y, fx), fy);
+  out[2] = smk_lerp(smk_lerp(t[0].z, t[1].z, fx), smk_lerp(t[2].z, t[3].z, fx), fy);
+}
+// the light-buffer colour over the sample of plane m at voxel coordinate p (R8kVolRen3D.cpp:1664-1676: light-buffer
+// coordinates; the buffer is the one slices < k left, k the plane's slice in the light's order)
+__device__ __forceinline__ void smk_shadow_term(const RenderParams &P, int m, float p0, float p1, float p2, float out[3]) {
+  const SmkShadowRays &sh = P.sh;
+  const float lw = __fmaf_rn(p0, sh.Wm[0], __fmaf_rn(p1, sh.Wm[1], __fmaf_rn(p2, sh.Wm[2], sh.Wm[3])));
+  const float lxx = __fmaf_rn(p0, sh.Xm[0], __fmaf_rn(p1, sh.Xm[1], __fmaf_rn(p2, sh.Xm[2], sh.Xm[3])));
+  const float lyy = __fmaf_rn(p0, sh.Ym[0], __fmaf_rn(p1, sh.Ym[1], __fmaf_rn(p2, sh.Ym[2], sh.Ym[3])));
+  const int k = sh.k0 + sh.dk * m;
+  smk_light_lookup(sh.hist + (size_t)(k - 1) * ((size_t)sh.LB * sh.LB), sh.LB, __fmaf_rn(__fdiv_rn(lxx, lw), sh.lscale, sh.lbias),
+                   __fmaf_rn(__fdiv_rn(lyy, lw), sh.lscale, sh.lbias), out);
+}
+
 // XCD-aware tile mapping: blocks are dealt round-robin over the 8 XCDs (bid % 8 shares an
 // XCD), so give each XCD one contiguous run of tiles -- neighbouring image tiles, which walk
 // neighbouring voxels, then share an L2.  Speed only; any placement is correct.

@@ -24,17 +24,13 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
   const smk_raycoef &rc = P.rc;
   const float px = __fmaf_rn((float)i + 0.5f, rc.pxs, rc.pxl);
   const float py = __fmaf_rn((float)j + 0.5f, rc.pys, rc.pyl);
-  float A[3], B[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    A[a] = __fmaf_rn(px, rc.Ax[a], __fmaf_rn(py, rc.Ay[a], rc.Ac[a]));
-    B[a] = __fmaf_rn(px, rc.Bx[a], __fmaf_rn(py, rc.By[a], rc.Bc[a]));
-  }
+  float A[3], B[3], tauA, dtau;  // (tauA, dtau: frames with shadows only, see smk_ray_AB)
+  const bool ray_ok = smk_ray_AB(P, px, py, A, B, tauA, dtau);
 
   // conservative plane range [m0,m1] from a slab test (+-2 planes of slack); the exact
   // per-sample inside test below is what decides membership
   float tenter = 0.0f, texit = (float)(rc.nplanes - 1);
-  bool empty = rc.nplanes <= 0;
+  bool empty = rc.nplanes <= 0 || !ray_ok;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     if (fabsf(B[a]) > 1e-20f) {
@@ -85,6 +81,8 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
     if (!in) continue;
     // free clip plane (glClipPlane semantics, NV20VolRen3D.cpp:346-357): fragments on its negative side do not exist
     if (P.cplane_on && !(__fmaf_rn(p0, P.cplane[0], __fmaf_rn(p1, P.cplane[1], __fmaf_rn(p2, P.cplane[2], P.cplane[3]))) >= 0.0f)) continue;
+    if (P.sh.on && !smk_tau_ok(tauA, dtau, m)) continue;  // (half-angle slices: a sample behind the eye does not exist)
+    const float q0 = p0, q1 = p1, q2 = p2;  // (the sample's own position: where its light-buffer lookup is made)
 
     if (P.pert_on) {
       if (TF != 0 && P.bricks_dil != nullptr) {
@@ -182,15 +180,22 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
     if (!smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col)) continue;
 
     float4 src;
+    // frames with shadows: the light-buffer colour over the sample, as the slices nearer the light left it (smk_shadow.hip)
+    float shadow[3];
+    const float *shp = nullptr;
+    if (TF != 0 && P.sh.on) {
+      smk_shadow_term(P, m, q0, q1, q2, shadow);
+      shp = shadow;
+    }
     if (TF == 0) {
       src = col;
     } else if (SH == 0) {
-      src = smk_shade_sample<0>(P, col, 0.f, 0.f, 0.f, 0.f);
+      src = smk_shade_sample<0>(P, col, 0.f, 0.f, 0.f, 0.f, shp);
     } else {
       float n0 = smk_nrm(k000.nb, k100.nb, k010.nb, k110.nb, k001.nb, k101.nb, k011.nb, k111.nb, 0, fx, fy, fz);
       float n1 = smk_nrm(k000.nb, k100.nb, k010.nb, k110.nb, k001.nb, k101.nb, k011.nb, k111.nb, 1, fx, fy, fz);
       float n2 = smk_nrm(k000.nb, k100.nb, k010.nb, k110.nb, k001.nb, k101.nb, k011.nb, k111.nb, 2, fx, fy, fz);
-      src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1);
+      src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1, shp);
     }
     if (P.blend == SMK_BLEND_FRONT_TO_BACK) {
       // C += (1-A) src   (GL_ONE_MINUS_DST_ALPHA, GL_ONE)
@@ -236,17 +241,14 @@ __global__ __launch_bounds__(256) void smk_k_count_inside(const RenderParams P, 
     const smk_raycoef &rc = P.rc;
     const float px = __fmaf_rn((float)i + 0.5f, rc.pxs, rc.pxl);
     const float py = __fmaf_rn((float)j + 0.5f, rc.pys, rc.pyl);
-    float A[3], B[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      A[a] = __fmaf_rn(px, rc.Ax[a], __fmaf_rn(py, rc.Ay[a], rc.Ac[a]));
-      B[a] = __fmaf_rn(px, rc.Bx[a], __fmaf_rn(py, rc.By[a], rc.Bc[a]));
-    }
-    for (int m = 0; m < rc.nplanes; ++m) {
+    float A[3], B[3], tauA, dtau;
+    const bool ray_ok = smk_ray_AB(P, px, py, A, B, tauA, dtau);
+    for (int m = 0; m < (ray_ok ? rc.nplanes : 0); ++m) {
       const float p0 = __fmaf_rn((float)m, B[0], A[0]), p1 = __fmaf_rn((float)m, B[1], A[1]), p2 = __fmaf_rn((float)m, B[2], A[2]);
       bool in = (p0 >= P.lo[0] && (p0 < P.hi[0] || (P.top[0] && p0 <= P.hi[0]))) && (p1 >= P.lo[1] && (p1 < P.hi[1] || (P.top[1] && p1 <= P.hi[1]))) &&
                 (p2 >= P.lo[2] && (p2 < P.hi[2] || (P.top[2] && p2 <= P.hi[2])));
       if (in && P.cplane_on) in = __fmaf_rn(p0, P.cplane[0], __fmaf_rn(p1, P.cplane[1], __fmaf_rn(p2, P.cplane[2], P.cplane[3]))) >= 0.0f;
+      if (in && P.sh.on) in = smk_tau_ok(tauA, dtau, m);
       n += in ? 1u : 0u;
     }
   }

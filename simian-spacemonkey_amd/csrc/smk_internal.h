@@ -13,7 +13,24 @@
 #define SMK_MAX_RANKS 8
 #define SMK_TIMING_RING 64
 #define SMK_BRICK_LOG2 3   // bricks of 8x8x8 cells (smk_bricks.hip)
+#define SMK_SHADOW_BOX_EPS 0.0009765625f  // voxels: frames with shadows test an eye sample against the box widened by this (smk_api.hip)
 #define SMK_STATUS_RING 8  // frames whose slice-ring status stays readable (smk_frame_failed)
+
+// Eye rays of a frame with shadows (half-angle slicing, smk_shadow.hip).  The slice planes are not perpendicular to the
+// view axis, so a ray's coefficients are not affine in the pixel coordinate; they are (smk_ray_AB, smk_device.h)
+//   D_a = fma(px, Dx_a, fma(py, Dy_a, Dc_a)),  nD = fma(px, nDx, fma(py, nDy, nDc)),
+//   tauA = numA / nD, dtau = dB / nD,  A_a = fma(tauA, D_a, Ec_a),  B_a = dtau * D_a
+// and plane m = 0..nplanes-1, counted FROM THE EYE, holds the sample fma(m, B, A) where fma(m, dtau, tauA) is positive and
+// finite (a sample behind the eye does not exist).  Plane m is slice k = k0 + dk m of the light's order (k = 1..nslices away
+// from the light); its sample is shaded under the light buffer as slices < k left it: hist[k - 1].
+struct SmkShadowRays {
+  int on;  // 0: the affine coefficients of smk_raycoef
+  float Ec[3], Dc[3], Dx[3], Dy[3], nDc, nDx, nDy;
+  float numA, dB;
+  int k0, dk, LB;
+  float Xm[4], Ym[4], Wm[4], lscale, lbias;
+  const float4 *hist;  // [nslices + 1][LB][LB]
+};
 
 // Everything a render kernel needs, passed by value as the kernarg (wave-uniform => SGPRs).
 struct RenderParams {
@@ -50,6 +67,7 @@ struct RenderParams {
   const unsigned char *bricks_dil;  // the same, each flag spread over the bricks a perturbed fetch can reach from there, or null
   // ---- camera / sample placement
   smk_raycoef rc;
+  SmkShadowRays sh;
   int W, H;
   float znear;
   // ---- shading
@@ -315,8 +333,7 @@ hipError_t smk_launch_count_inside(const RenderParams &P, unsigned long long *d_
 // one launch per slice (smk_shadow.hip); L0 cleared by the caller
 hipError_t smk_launch_shadow(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, int shade_kind,
                              float4 *L0, float4 *L1, unsigned *barrier /* one device word for the fused launch's grid barrier, or null */, hipStream_t s);
-hipError_t smk_launch_shadow_march(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, int shade_kind,
-                                   float4 *hist, hipStream_t s);
+hipError_t smk_launch_shadow_march(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, float4 *hist, hipStream_t s);
 // returns hipErrorNotSupported (and *why) when the frame must use the gather kernel
 hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kind, int opt_T, int opt_tile, int forced,
                            const void *vox_native, const void *vox_xmajor, SlabAux *aux, const char **why,

@@ -24,7 +24,8 @@ struct ShadowSlice {
   smk_shadowcoef sc;
   const float4 *Lprev;  // [LB][LB] light buffer after the previous slices
   float4 *Lnext;        // ... after this one
-  float num, lnum;      // numerators of this slice's ray parameters (fma(k, dnum, num0), fma(k, ldnum, lnum0))
+  float lnum;           // numerator of this slice's light-ray parameter, fma(k, ldnum, lnum0)
+  int k;                // the slice, 1..nslices in the light's order
   int eye_bx, eye_blocks, light_bx;  // 16x16-pixel blocks: eye grid width, eye block count, light grid width
 };
 
@@ -152,17 +153,19 @@ template <int DT, int TF, int SH, bool COH = false>
 __device__ __forceinline__ void shadow_eye_pixel(const RenderParams &P, const ShadowSlice &Q, int i, int j) {
   const smk_shadowcoef &sc = Q.sc;
   if (i >= P.W || j >= P.H) return;
-  const float px = __fmaf_rn((float)i + 0.5f, sc.pxs, sc.pxl), py = __fmaf_rn((float)j + 0.5f, sc.pys, sc.pyl);
-  const float nD = __fmaf_rn(px, sc.nDx, __fmaf_rn(py, sc.nDy, sc.nDc));
-  const float tau = __fdiv_rn(Q.num, nD);
-  if (!(tau > 0.0f) || isinf(tau)) return;
+  // the sample of this pixel's ray in slice k: plane m of the ray, counted from the eye (SmkShadowRays, smk_ray_AB) -- the
+  // very chain the ray-marchers evaluate
+  const float px = __fmaf_rn((float)i + 0.5f, P.rc.pxs, P.rc.pxl), py = __fmaf_rn((float)j + 0.5f, P.rc.pys, P.rc.pyl);
+  float A[3], B[3], tauA, dtau;
+  if (!smk_ray_AB(P, px, py, A, B, tauA, dtau)) return;
+  const int m = P.sh.dk > 0 ? Q.k - P.sh.k0 : P.sh.k0 - Q.k;
+  if (!smk_tau_ok(tauA, dtau, m)) return;
   float p[3];
   bool in = true;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const float D = __fmaf_rn(px, sc.Dx[a], __fmaf_rn(py, sc.Dy[a], sc.Dc[a]));
-    p[a] = __fmaf_rn(tau, D, sc.Ec[a]);
-    in = in && p[a] >= -0.5f && p[a] <= (float)P.N[a] - 0.5f;
+    p[a] = __fmaf_rn((float)m, B[a], A[a]);
+    in = in && p[a] >= P.lo[a] && p[a] <= P.hi[a];  // (the box, 2^-10 voxels wide: smk_api.hip)
   }
   if (!in) return;
   const size_t o = (size_t)j * P.W + i;
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256) void smk_k_shadow_fused(const RenderParams P, 
   const int lx = (wave & 1) * 8 + (lane & 7), ly = (wave >> 1) * 8 + (lane >> 3);
   const int nlb = Q.light_bx * Q.light_bx, nblocks = Q.eye_blocks + nlb;
   for (int k = 1; k <= sc.nslices; ++k) {
-    Q.num = __fmaf_rn((float)k, sc.dnum, sc.num0);
+    Q.k = k;
     Q.lnum = __fmaf_rn((float)k, sc.ldnum, sc.lnum0);
     Q.Lprev = (k & 1) ? L0 : L1;
     Q.Lnext = (k & 1) ? L1 : L0;
@@ -299,8 +302,10 @@ __global__ __launch_bounds__(256) void smk_k_shadow_fused(const RenderParams P, 
 // recurrence over slices is a ray-march per TEXEL along its light ray -- no launch boundary needed -- provided every slice's
 // light buffer is kept for the eye pass to look up: hist[k][LB][LB], k = 0..nslices (288 GB of HBM: 512 slices of a 512^2
 // buffer are 2.1 GB).  With the history in memory an eye pixel depends on itself alone, too: the eye pass is a ray-march per
-// PIXEL.  Two launches instead of nslices, the very same operations per sample in the very same order (the per-slice
-// functions above, with the running value in registers): frames and light buffers are bit-identical to the per-slice form.
+// PIXEL -- an ordinary frame of the ray-marchers (slice-ring or gather kernel) over the half-angle slices, whose shading looks
+// the light buffer of the sample's slice up (smk_shadow_term).  Light buffers are bit-identical to the per-slice form's;
+// frames too where the eye pass keeps the blend's order (a light behind the viewer, no depth segments), and differ by the
+// association of the blend otherwise.
 //
 // Conservative range of slices whose sample E + tau(k) D, tau(k) = fma(k, dnum, num0) / den, can lie inside the volume with
 // tau > 0: solved in real arithmetic on a box widened by 0.05 voxels, +- 2 slices; anything doubtful gives the whole range.
@@ -398,98 +403,24 @@ __global__ __launch_bounds__(256) void smk_k_shadow_light_march(const RenderPara
   }
 }
 
-// the eye march: one thread per pixel, the slices in the order of the per-slice launches (away from the light), the frame
-// value in registers; slice k is shaded under hist[k - 1]
-template <int DT, int TF, int SH>
-__global__ __launch_bounds__(256) void smk_k_shadow_eye_march(const RenderParams P, const ShadowSlice Q, const float4 *hist) {
-  const smk_shadowcoef &sc = Q.sc;
-  int tile;
-  if (!shadow_tile_of_block((int)blockIdx.x, Q.eye_blocks, tile)) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = (tile % Q.eye_bx) * 16 + (wave & 1) * 8 + (lane & 7), j = (tile / Q.eye_bx) * 16 + (wave >> 1) * 8 + (lane >> 3);
-  const bool live = i < P.W && j < P.H;
-  const float px = __fmaf_rn((float)i + 0.5f, sc.pxs, sc.pxl), py = __fmaf_rn((float)j + 0.5f, sc.pys, sc.pyl);
-  const float nD = __fmaf_rn(px, sc.nDx, __fmaf_rn(py, sc.nDy, sc.nDc));
-  float D[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) D[a] = __fmaf_rn(px, sc.Dx[a], __fmaf_rn(py, sc.Dy[a], sc.Dc[a]));
-  int k0, k1;
-  shadow_k_range(P, sc.num0, sc.dnum, nD, D, sc.Ec, sc.nslices, k0, k1);
-  if (!live) k1 = 0;
-  // the wave walks the slices together (its 64 samples of a slice lie in one thin slab of the volume)
-  int klo = k1 >= k0 ? k0 : 0x7fffffff, khi = k1 >= k0 ? k1 : -0x7fffffff;
-  for (int off = 32; off > 0; off >>= 1) {
-    klo = min(klo, __shfl_xor(klo, off));
-    khi = max(khi, __shfl_xor(khi, off));
-  }
-  const size_t nl = (size_t)sc.LB * sc.LB;
-  float4 C = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = klo; k <= khi; ++k) {
-    if (!__any(k <= k1)) break;  // every ray of the wave is past its range or saturated
-    if (k < k0 || k > k1) continue;
-    const float tau = __fdiv_rn(__fmaf_rn((float)k, sc.dnum, sc.num0), nD);
-    if (!(tau > 0.0f) || isinf(tau)) continue;
-    float p[3];
-    bool in = true;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      p[a] = __fmaf_rn(tau, D[a], sc.Ec[a]);
-      in = in && p[a] >= -0.5f && p[a] <= (float)P.N[a] - 0.5f;
-    }
-    if (!in) continue;
-    if (shadow_brick_empty(P, p[0], p[1], p[2])) continue;
-    float ch0, ch1, ch2, ch3, n0 = 0.f, n1 = 0.f, n2 = 0.f;
-    shadow_fetch<DT, TF, SH != 0>(P, p[0], p[1], p[2], ch0, ch1, ch2, ch3, n0, n1, n2);
-    float4 col;
-    if (!shadow_maybe_visible<TF>(P, ch0, ch1)) continue;
-    if (!smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col)) continue;
-    const float lw = __fmaf_rn(p[0], sc.Wm[0], __fmaf_rn(p[1], sc.Wm[1], __fmaf_rn(p[2], sc.Wm[2], sc.Wm[3])));
-    const float lxx = __fmaf_rn(p[0], sc.Xm[0], __fmaf_rn(p[1], sc.Xm[1], __fmaf_rn(p[2], sc.Xm[2], sc.Xm[3])));
-    const float lyy = __fmaf_rn(p[0], sc.Ym[0], __fmaf_rn(p[1], sc.Ym[1], __fmaf_rn(p[2], sc.Ym[2], sc.Ym[3])));
-    float shadow[3];
-    shadow_lookup<false>(hist + (size_t)(k - 1) * nl, sc.LB, __fmaf_rn(__fdiv_rn(lxx, lw), sc.lscale, sc.lbias),
-                         __fmaf_rn(__fdiv_rn(lyy, lw), sc.lscale, sc.lbias), shadow);
-    const float4 src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1, shadow);
-    if (sc.front_to_back) {
-      const float w = 1.0f - C.w;
-      C.x = __fmaf_rn(w, src.x, C.x);
-      C.y = __fmaf_rn(w, src.y, C.y);
-      C.z = __fmaf_rn(w, src.z, C.z);
-      C.w = __fmaf_rn(w, src.w, C.w);
-      if (C.w == 1.0f) k1 = k;  // exact: every later weight (1-A) is 0 (the per-slice form leaves such a pixel alone)
-    } else {
-      const float w = 1.0f - src.w;
-      C.x = __fmaf_rn(w, C.x, src.x);
-      C.y = __fmaf_rn(w, C.y, src.y);
-      C.z = __fmaf_rn(w, C.z, src.z);
-      C.w = __fmaf_rn(w, C.w, src.w);
-    }
-  }
-  if (live) P.out[(size_t)j * P.W + i] = C;
-}
-
-template <int DT, int TF, int SH>
+template <int DT, int TF>
 static hipError_t run_march(const RenderParams &P, ShadowSlice Q, float4 *hist, hipStream_t s) {
   const smk_shadowcoef &sc = Q.sc;
-  Q.eye_bx = (P.W + 15) / 16;
-  Q.eye_blocks = Q.eye_bx * ((P.H + 15) / 16);
   Q.light_bx = (sc.LB + 15) / 16;
-  const int lblocks = 8 * ((Q.light_bx * Q.light_bx + 7) / 8), eblocks = 8 * ((Q.eye_blocks + 7) / 8);
+  const int lblocks = 8 * ((Q.light_bx * Q.light_bx + 7) / 8);
   hipLaunchKernelGGL((smk_k_shadow_light_march<DT, TF>), dim3(lblocks), dim3(256), 0, s, P, Q, hist);
-  hipLaunchKernelGGL((smk_k_shadow_eye_march<DT, TF, SH>), dim3(eblocks), dim3(256), 0, s, P, Q, (const float4 *)hist);
   return hipGetLastError();
 }
 
-// hist: [nslices + 1][LB][LB] texels; the light buffer the frame leaves is hist[nslices]
-hipError_t smk_launch_shadow_march(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, int shade_kind,
-                                   float4 *hist, hipStream_t s) {
+// The light march alone: hist = [nslices + 1][LB][LB] texels, hist[k] = the light buffer after slices 1..k.  The eye pass is
+// then an ordinary frame of the ray-marchers over the half-angle slices (P.sh, smk_api.hip).
+hipError_t smk_launch_shadow_march(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, float4 *hist, hipStream_t s) {
   ShadowSlice Q;
   memset(&Q, 0, sizeof Q);
   Q.sc = sc;
-#define CASE(D, T, S) \
-  if (dtype == D && tf_mode == T && shade_kind == S) return run_march<D, T, S>(P, Q, hist, s);
-  CASE(0, 1, 0) CASE(0, 1, 1) CASE(0, 2, 0) CASE(0, 2, 1)
-  CASE(1, 1, 0) CASE(1, 1, 1) CASE(1, 2, 0) CASE(1, 2, 1)
+#define CASE(D, T) \
+  if (dtype == D && tf_mode == T) return run_march<D, T>(P, Q, hist, s);
+  CASE(0, 1) CASE(0, 2) CASE(1, 1) CASE(1, 2)
 #undef CASE
   return hipErrorNotSupported;
 }
@@ -531,7 +462,7 @@ static hipError_t run(const RenderParams &P, ShadowSlice Q, float4 *L0, float4 *
     }
   }
   for (int k = 1; k <= sc.nslices; ++k) {
-    Q.num = fmaf((float)k, sc.dnum, sc.num0);
+    Q.k = k;
     Q.lnum = fmaf((float)k, sc.ldnum, sc.lnum0);
     Q.Lprev = (k & 1) ? L0 : L1;
     Q.Lnext = (k & 1) ? L1 : L0;

@@ -322,15 +322,11 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   const smk_raycoef &rc = P.rc;
   const float px = __fmaf_rn((float)i + 0.5f, rc.pxs, rc.pxl);
   const float py = __fmaf_rn((float)j + 0.5f, rc.pys, rc.pyl);
-  float A[3], B[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    A[a] = __fmaf_rn(px, rc.Ax[a], __fmaf_rn(py, rc.Ay[a], rc.Ac[a]));
-    B[a] = __fmaf_rn(px, rc.Bx[a], __fmaf_rn(py, rc.By[a], rc.Bc[a]));
-  }
+  float A[3], B[3], tauA, dtau;  // (tauA, dtau: frames with shadows only -- the ray parameter of plane q is fma(q, dtau, tauA), smk_ray_AB)
+  const bool ray_ok = smk_ray_AB(P, px, py, A, B, tauA, dtau);
   // conservative plane range (identical to the gather kernel)
   float tenter = 0.0f, texit = (float)(rc.nplanes - 1);
-  bool empty = rc.nplanes <= 0 || !live;
+  bool empty = rc.nplanes <= 0 || !live || !ray_ok;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     if (fabsf(B[a]) > 1e-20f) {
@@ -360,6 +356,17 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       empty = true;
     }
   }
+  // Frames with shadows: a sample exists where its ray parameter fma(q, dtau, tauA) is positive -- monotone in q like the clip
+  // plane's value, folded into the range the same way.
+  if (P.sh.on && ray_ok) {
+    if (fabsf(dtau) > 1e-30f) {
+      const float tz = -tauA / dtau;
+      if (dtau > 0.0f) tenter = fmaxf(tenter, tz - 2.0f);
+      else texit = fminf(texit, tz + 2.0f);
+    } else if (!(tauA > 0.0f)) {
+      empty = true;
+    }
+  }
   int m = (int)floorf(fmaxf(tenter, 0.0f));
   int m1 = (int)ceilf(fminf(texit, (float)(rc.nplanes - 1)));
   if (empty || !(tenter <= texit)) m1 = m - 1;
@@ -377,6 +384,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
                  (int)(smk_clampf(p2, P.lo[2], P.hin[2]) == p2)) != 0;
       // (the gather kernel's own fma chain for the plane: the same samples pass, bit for bit)
       if (P.cplane_on) in = in && __fmaf_rn(p0, P.cplane[0], __fmaf_rn(p1, P.cplane[1], __fmaf_rn(p2, P.cplane[2], P.cplane[3]))) >= 0.0f;
+      if (P.sh.on) in = in && smk_tau_ok(tauA, dtau, q);
       return in;
     };
     int mf = m1 + 1, ml = m - 1;
@@ -512,11 +520,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       int ci = min(tx * Q.tw + ((c & 1) ? Q.tw - 1 : 0), P.W - 1);
       int cj = min(ty * Q.th + ((c & 2) ? Q.th - 1 : 0), P.H - 1);
       float cx = __fmaf_rn((float)ci + 0.5f, rc.pxs, rc.pxl), cy = __fmaf_rn((float)cj + 0.5f, rc.pys, rc.pyl);
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        cA[c][a] = __fmaf_rn(cx, rc.Ax[a], __fmaf_rn(cy, rc.Ay[a], rc.Ac[a]));
-        cB[c][a] = __fmaf_rn(cx, rc.Bx[a], __fmaf_rn(cy, rc.By[a], rc.Bc[a]));
-      }
+      float cta, cdt;
+      (void)smk_ray_AB(P, cx, cy, cA[c], cB[c], cta, cdt);  // (the launcher declines frames whose rays can run parallel to the slices)
     }
     if (Q.use_ah)
       for (int e = tid; e < P.sv; e += NTH) ah[e] = smk_ub(P.tf_h[e], 3);
@@ -1350,10 +1355,19 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
               col.z = slab_tex_chan(tx4, 2);
             }
             float4 src;
+            // frames with shadows: the light-buffer colour over the sample, as the slices nearer the light left it
+            // (smk_shadow.hip; the sample's own position: the gather kernel's fma chain)
+            float shadow[3];
+            const float *shp = nullptr;
+            if (TF != 0 && P.sh.on) {
+              const float mf = (float)m;
+              smk_shadow_term(P, m, __fmaf_rn(mf, B[0], A[0]), __fmaf_rn(mf, B[1], A[1]), __fmaf_rn(mf, B[2], A[2]), shadow);
+              shp = shadow;
+            }
             if (TF == 0) {
               src = col;  // the 1-D colour table's entries are premultiplied (TLUT.cpp:65-71), as in the gather kernel
             } else if (SH == 0) {
-              src = smk_shade_sample<0>(P, col, 0.f, 0.f, 0.f, 0.f);
+              src = smk_shade_sample<0>(P, col, 0.f, 0.f, 0.f, 0.f, shp);
             } else {
               uint32_t nb[8];  // the packed normals of the same corners: second batch, or already here (EARLY)
               if constexpr (EARLY) {
@@ -1369,7 +1383,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
               float n1 = smk_nrm(NB(0, 0, 0), NB(1, 0, 0), NB(0, 1, 0), NB(1, 1, 0), NB(0, 0, 1), NB(1, 0, 1), NB(0, 1, 1), NB(1, 1, 1), 1, fx, fy, fz);
               float n2 = smk_nrm(NB(0, 0, 0), NB(1, 0, 0), NB(0, 1, 0), NB(1, 1, 0), NB(0, 0, 1), NB(1, 0, 1), NB(0, 1, 1), NB(1, 1, 1), 2, fx, fy, fz);
 #undef NB
-              src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1);
+              src = smk_shade_sample<SH>(P, col, n0, n1, n2, ch1, shp);
             }
             // first-hit depth (the gather kernel's `first`): the first sample that passes classification finds the accumulated
             // alpha still exactly 0, no later one does -- nothing is carried through the loop for it
@@ -1513,9 +1527,32 @@ __global__ __launch_bounds__(256) void smk_k_slab_merge(const int2 *list, int tw
   }
 }
 
+// a ray's coefficients on the host, for planning: at a real-valued position (px, py) of the image plane, in double -- the
+// kernels' float chains (smk_ray_AB) round differently by less than the planning's own slack
+static void host_ray_at(const RenderParams &P, double px, double py, double A[3], double B[3]) {
+  const smk_raycoef &rc = P.rc;
+  if (!P.sh.on) {
+    for (int a = 0; a < 3; ++a) {
+      A[a] = px * rc.Ax[a] + py * rc.Ay[a] + rc.Ac[a];
+      B[a] = px * rc.Bx[a] + py * rc.By[a] + rc.Bc[a];
+    }
+    return;
+  }
+  const SmkShadowRays &sh = P.sh;  // frames with shadows: half-angle slices (smk_internal.h)
+  const double nD = px * sh.nDx + py * sh.nDy + sh.nDc, tauA = sh.numA / nD, dtau = sh.dB / nD;
+  for (int a = 0; a < 3; ++a) {
+    const double D = px * sh.Dx[a] + py * sh.Dy[a] + sh.Dc[a];
+    A[a] = sh.Ec[a] + tauA * D;
+    B[a] = dtau * D;
+  }
+}
 static void host_ray(const RenderParams &P, int i, int j, double A[3], double B[3]) {
   const smk_raycoef &rc = P.rc;
-  float px = fmaf((float)i + 0.5f, rc.pxs, rc.pxl), py = fmaf((float)j + 0.5f, rc.pys, rc.pyl);
+  const float px = fmaf((float)i + 0.5f, rc.pxs, rc.pxl), py = fmaf((float)j + 0.5f, rc.pys, rc.pyl);
+  if (P.sh.on) {
+    host_ray_at(P, px, py, A, B);
+    return;
+  }
   for (int a = 0; a < 3; ++a) {
     A[a] = fmaf(px, rc.Ax[a], fmaf(py, rc.Ay[a], rc.Ac[a]));
     B[a] = fmaf(px, rc.Bx[a], fmaf(py, rc.By[a], rc.Bc[a]));
@@ -1567,9 +1604,8 @@ static bool slab_bundle_slice_range_fast(const RenderParams &P, double fx0, doub
     const double px = fx[c] * (double)rc.pxs + (double)rc.pxl, py = fy[c] * (double)rc.pys + (double)rc.pyl;
     double A[3], B[3], te = -1e300, tx = 1e300;
     int ie = -1, ix = -1;
+    host_ray_at(P, px, py, A, B);
     for (int a = 0; a < 3; ++a) {
-      A[a] = px * rc.Ax[a] + py * rc.Ay[a] + rc.Ac[a];
-      B[a] = px * rc.Bx[a] + py * rc.By[a] + rc.Bc[a];
       const double lo = (double)P.lo[a] - eps, hi = (double)P.hi[a] + eps;
       if (fabs(B[a]) < 1e-12) {
         if (A[a] < lo || A[a] > hi) return false;
@@ -1615,8 +1651,10 @@ bool slab_bundle_slice_range_exact(const RenderParams &P, double fx0, double fy0
   double cen[3] = {0, 0, 0}, scale = 1.0;
   for (int c = 0; c < 4; ++c) {
     const double px = fx[c] * (double)rc.pxs + (double)rc.pxl, py = fy[c] * (double)rc.pys + (double)rc.pyl;
+    double Ar[3], Br[3];
+    host_ray_at(P, px, py, Ar, Br);
     for (int a = 0; a < 3; ++a) {
-      const double A = px * rc.Ax[a] + py * rc.Ay[a] + rc.Ac[a], B = px * rc.Bx[a] + py * rc.By[a] + rc.Bc[a];
+      const double A = Ar[a], B = Br[a];
       F[c][0].v[a] = A + q0 * B;
       F[c][1].v[a] = A + q1 * B;
       cen[a] += (F[c][0].v[a] + F[c][1].v[a]) / 8.0;
@@ -1790,6 +1828,21 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
   if (P.N[0] < 2 || P.N[1] < 2 || P.N[2] < 2) { *why = "volume thinner than 2 voxels"; return hipErrorNotSupported; }
   if (dtype == 1 && !P.n_in_w) { *why = "4-channel f32 voxels"; return hipErrorNotSupported; }
   if (P.rc.nplanes <= 0) { *why = "no planes"; return hipErrorNotSupported; }
+  if (P.sh.on) {
+    // frames with shadows: the component of a ray along the slice normal is affine in the pixel coordinate; where it keeps
+    // its sign over the viewport's corners no ray runs parallel to the slices (the planning divides by it)
+    double lo_n = 1e300, hi_n = -1e300;
+    for (int c = 0; c < 4; ++c) {
+      const double px = ((c & 1) ? (double)P.W : 0.0) * P.rc.pxs + P.rc.pxl, py = ((c & 2) ? (double)P.H : 0.0) * P.rc.pys + P.rc.pyl;
+      const double nD = px * P.sh.nDx + py * P.sh.nDy + P.sh.nDc;
+      lo_n = std::min(lo_n, nD);
+      hi_n = std::max(hi_n, nD);
+    }
+    if (!(lo_n > 0 || hi_n < 0) || std::min(fabs(lo_n), fabs(hi_n)) < 1e-6 * std::max(fabs(lo_n), fabs(hi_n))) {
+      *why = "half-angle slices parallel to some eye ray";
+      return hipErrorNotSupported;
+    }
+  }
 
   // principal axis from the central ray
   double Ac[3], Bc[3];
@@ -1919,9 +1972,16 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
       smk_raycoef rc;
       int W, H, tw, th, as, au, av, dir, N[3], top[3];
       float lo[3], hi[3], hin[3];
+      float sh[18];  // frames with shadows: the eye rays' coefficients (SmkShadowRays), else zeros
     } key;
     memset(&key, 0, sizeof key);
     key.rc = P.rc;
+    if (P.sh.on) {
+      const SmkShadowRays &h = P.sh;
+      const float v[18] = {1.0f, h.Ec[0], h.Ec[1], h.Ec[2], h.Dc[0], h.Dc[1], h.Dc[2], h.Dx[0], h.Dx[1], h.Dx[2], h.Dy[0], h.Dy[1], h.Dy[2],
+                           h.nDc, h.nDx, h.nDy, h.numA, h.dB};
+      memcpy(key.sh, v, sizeof v);
+    }
     key.W = P.W; key.H = P.H; key.tw = tw; key.th = th; key.as = as; key.au = Q.au; key.av = Q.av; key.dir = Q.dir;
     for (int a = 0; a < 3; ++a) { key.N[a] = P.N[a]; key.top[a] = P.top[a]; key.lo[a] = P.lo[a]; key.hi[a] = P.hi[a]; key.hin[a] = P.hin[a]; }
     int slot = -1;

@@ -157,7 +157,7 @@ def test_shadow_frames(R, f32):
         R.set_option("bricks", b)
         push_scene(R, sc)
         frame = R.render()
-        assert R.last_frame_info()[0] == 3
+        assert R.last_frame_info()[0] in (1, 2)
         out[b] = (frame, R.light_buffer())
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
     assert out[0][0][..., 3].max() > 0.05 and out[0][1][..., 3].max() > 0.05

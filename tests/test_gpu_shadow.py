@@ -33,7 +33,7 @@ def _check(R, sc, tol=TOL):
     ref, refL = sc.render_shadow()
     got = R.render()
     gotL = R.light_buffer()
-    assert R.last_frame_info()[0] == 3
+    assert R.last_frame_info()[0] in (1, 2)   # (the eye pass is a frame of the ray-marchers; 3 = a launch per slice)
     assert ref[..., 3].max() > 0.05 and refL[..., 3].max() > 0.05, "vacuous scene"
     assert gotL.shape == refL.shape
     eL, e = np.abs(gotL - refL).max(), np.abs(got - ref).max()
@@ -140,9 +140,9 @@ def test_all_slices_in_one_cooperative_launch(R):
     try:
         b = R.render()
         lb = R.light_buffer()
+        assert R.last_frame_info()[0] == 3
     finally:
         R.set_option("shadow_fused", 0)
-    assert R.last_frame_info()[0] == 3
     assert np.array_equal(a, b) and np.array_equal(la, lb)
 
 
@@ -151,21 +151,35 @@ def test_all_slices_in_one_cooperative_launch(R):
                                                  ("cfg4", True, 1, "side")])
 def test_two_marches_equal_a_launch_per_slice(R, light, kind, f32, shade, pose):
     """The default since round 3: one march per light-buffer texel (its value depends on itself alone from slice to slice)
-    that keeps every slice's light buffer, then one march per eye pixel that looks slice k's shading up in buffer k - 1 --
-    two launches instead of one per slice, the same operations in the same order: frame and light buffer bit-identical to
-    the per-slice launches (option shadow_march 0), for lights on either side of the viewer (both blend orders)."""
+    that keeps every slice's light buffer, then the eye pass as an ordinary frame of the ray-marchers over the half-angle
+    slices, looking slice k's shading up in buffer k - 1.  The same samples and the same operations as a launch per slice
+    (option shadow_march 0): light buffers bit-identical; frames bit-identical where the slices run away from the viewer
+    (the blend keeps its order), and within the re-association of the blend where they run towards the viewer (the marchers
+    composite front to back what the per-slice form blends back to front).  Both ray-marchers agree bit for bit."""
     sc = make_scene(kind, n=48, size=112, steps=150, f32=f32, shade=shade, pose=pose)
     sc.light_pos = LIGHTS[light]
     sc.shadow = (96, 0.7)
     push_scene(R, sc)
-    a = R.render()
-    la = R.light_buffer()
-    assert R.last_frame_info()[0] == 3
-    R.set_option("shadow_march", 0)
+    f2b = R.shadowcoef().front_to_back
+    out = {}
     try:
+        for kern in (1, 2):
+            R.set_option("kernel", kern)
+            out[kern] = (R.render(), R.light_buffer())
+            assert R.last_frame_info()[0] == kern
+        R.set_option("kernel", 0)
+        R.set_option("shadow_march", 0)
         b = R.render()
         lb = R.light_buffer()
+        assert R.last_frame_info()[0] == 3
     finally:
         R.set_option("shadow_march", 1)
-    assert a[..., 3].max() > 0.05 and la[..., 3].max() > 0.05, "vacuous scene"
-    assert np.array_equal(a, b) and np.array_equal(la, lb)
+        R.set_option("kernel", 0)
+    assert b[..., 3].max() > 0.05 and lb[..., 3].max() > 0.05, "vacuous scene"
+    assert np.array_equal(out[1][0], out[2][0])
+    for kern in (1, 2):
+        assert np.array_equal(out[kern][1], lb)
+        if f2b:
+            assert np.array_equal(out[kern][0], b)
+        else:
+            assert np.abs(out[kern][0] - b).max() <= 2e-5

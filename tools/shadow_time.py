@@ -24,9 +24,11 @@ def main():
     frame = torch.zeros((1024 * 1024, 4), dtype=torch.float32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     keep = {}
-    for march in (1, 0, 1):
+    for name, march, kernel in (("two marches, eye pass on the slice-ring kernel", 1, 2), ("two marches, eye pass on the gather kernel", 1, 1),
+                                ("a launch per slice", 0, 0), ("auto", 1, 0)):
         r.set_option("shadow_march", march)
-        for _ in range(3):
+        r.set_option("kernel", kernel)
+        for _ in range(40 if kernel != 1 else 3):
             r.render_device(frame.data_ptr(), None, st)
         torch.cuda.synchronize()
         r.timing_reset()
@@ -34,10 +36,13 @@ def main():
             r.render_device(frame.data_ptr(), None, st)
         torch.cuda.synchronize()
         kms, _ = r.timing_read()
-        keep[march] = (frame.clone(), torch.from_numpy(r.light_buffer()))
-        print("shadow_march %d: %.3f ms per frame (kernel id %d)" % (march, kms, r.last_frame_info()[0]), flush=True)
-    print("frames identical: %s   light buffers identical: %s   max alpha %.3f" % (
-        bool((keep[0][0] == keep[1][0]).all()), bool((keep[0][1] == keep[1][1]).all()), float(keep[1][0][:, 3].max())), flush=True)
+        keep[name] = (frame.clone(), torch.from_numpy(r.light_buffer()))
+        print("%-48s %.3f ms per frame (kernel id %d)" % (name, kms, r.last_frame_info()[0]), flush=True)
+    names = list(keep)
+    for n in names[1:]:
+        print("%s vs %s: frames max |diff| %.3g, light buffers identical: %s" % (
+            names[0], n, float((keep[names[0]][0] - keep[n][0]).abs().max()), bool((keep[names[0]][1] == keep[n][1]).all())), flush=True)
+    print("max alpha %.3f" % float(keep[names[0]][0][:, 3].max()), flush=True)
     r.close()
 
 
