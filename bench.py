@@ -440,10 +440,16 @@ def extra_legs(r, frame, work, steps):
     configure(r, "cfg3", n, 1024, 512)
     r.set_shading("r8k", (3.0, 4.0, -3.0), EYE, AT, xf, INTENS)
     r.set_shadow(1, 1024, 0.5)
-    run("cfg3_shadows", 1024, 512, "cfg3 with gluvv.light.shadow: 512 half-angle slices, each one launch = the eye pass over 1024^2 pixels "
-        "+ the light pass over a 512^2 light buffer (per-slice recurrence: no single-march form)")
-    out["cfg3_shadows"]["kernel"] = "shadow slices"
-    out["cfg3_shadows"]["roofline"] = None   # S dependent launches: bound by the per-slice gather latency and launch cadence, not by one stream
+    run("cfg3_shadows", 1024, 512, "cfg3 with gluvv.light.shadow: 512 half-angle slices; two marches -- one per texel of the 512^2 light buffer "
+        "(8 texels x 8 consecutive slices per wave), keeping every slice's buffer, then the eye pass as a frame of the ray-marcher over "
+        "the half-angle slices that looks each sample's slice up (smk_shadow.hip); kernel_ms covers both")
+    out["cfg3_shadows"]["kernel"] = "light march + " + out["cfg3_shadows"]["kernel"]
+    out["cfg3_shadows"]["roofline"] = None   # two kernels of different kinds (a gather-bound march, the slice-ring kernel): no single roofline
+    r.set_option("shadow_march", 0)
+    run("cfg3_shadows_per_slice", 1024, 512, "the same frame as a launch per slice (option shadow_march 0, the form of rounds 1-2)")
+    out["cfg3_shadows_per_slice"]["kernel"] = "shadow slices"
+    out["cfg3_shadows_per_slice"]["roofline"] = None
+    r.set_option("shadow_march", 1)
     r.set_shadow(0)
     # continuity with round 1: the north-star frame on round 1's input (smooth noisy shells, whose rays saturate
     # earlier: whole tiles stop streaming, which round 1's byte count ignored)

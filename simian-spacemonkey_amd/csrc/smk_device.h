@@ -281,8 +281,11 @@ __device__ __forceinline__ float smk_nrm(uint32_t a, uint32_t b, uint32_t c, uin
 // half-angle slices, the coefficients carry a division by the ray's component along the slice normal; `tauA`, `dtau` give
 // the ray parameter fma(m, dtau, tauA) of plane m, which must be positive and finite for the sample to exist (smk_tau_ok).
 // Returns false for a ray that runs parallel to the slices (no sample at all).
-__device__ __forceinline__ bool smk_ray_AB(const RenderParams &P, float px, float py, float A[3], float B[3], float &tauA, float &dtau) {
-  if (!P.sh.on) {
+// (SHD: a compile-time choice in the ray-marchers -- as a run-time test the shadow form cost the slice-ring kernel of the
+//  plain cfg 3 frame 3 VGPRs it does not have: spills, 2-8 % on every small-workgroup frame)
+template <bool SHD>
+__device__ __forceinline__ bool smk_ray_AB_t(const RenderParams &P, float px, float py, float A[3], float B[3], float &tauA, float &dtau) {
+  if (!SHD) {
     const smk_raycoef &rc = P.rc;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -306,6 +309,9 @@ __device__ __forceinline__ bool smk_ray_AB(const RenderParams &P, float px, floa
   }
   if (!ok) { tauA = -1.0f; dtau = 0.0f; }
   return ok;
+}
+__device__ __forceinline__ bool smk_ray_AB(const RenderParams &P, float px, float py, float A[3], float B[3], float &tauA, float &dtau) {
+  return P.sh.on ? smk_ray_AB_t<true>(P, px, py, A, B, tauA, dtau) : smk_ray_AB_t<false>(P, px, py, A, B, tauA, dtau);
 }
 __device__ __forceinline__ bool smk_tau_ok(float tauA, float dtau, int m) {
   const float t = __fmaf_rn((float)m, dtau, tauA);
@@ -337,7 +343,7 @@ __device__ __forceinline__ void smk_shadow_term(const RenderParams &P, int m, fl
   const float lxx = __fmaf_rn(p0, sh.Xm[0], __fmaf_rn(p1, sh.Xm[1], __fmaf_rn(p2, sh.Xm[2], sh.Xm[3])));
   const float lyy = __fmaf_rn(p0, sh.Ym[0], __fmaf_rn(p1, sh.Ym[1], __fmaf_rn(p2, sh.Ym[2], sh.Ym[3])));
   const int k = sh.k0 + sh.dk * m;
-  smk_light_lookup(sh.hist + (size_t)(k - 1) * ((size_t)sh.LB * sh.LB), sh.LB, __fmaf_rn(__fdiv_rn(lxx, lw), sh.lscale, sh.lbias),
+  smk_light_lookup(sh.hist + (size_t)(k - 1) * (size_t)sh.hstride, sh.LB, __fmaf_rn(__fdiv_rn(lxx, lw), sh.lscale, sh.lbias),
                    __fmaf_rn(__fdiv_rn(lyy, lw), sh.lscale, sh.lbias), out);
 }
 

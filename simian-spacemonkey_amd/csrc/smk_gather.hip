@@ -10,7 +10,8 @@
 // cache lines) and walk the volume together.
 #include "smk_device.h"
 
-template <int DT, int TF, int SH>
+// SHD: the frame's planes are the half-angle slices of a frame with shadows (SmkShadowRays): the eye pass of smk_shadow.hip
+template <int DT, int TF, int SH, bool SHD = false>
 __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
   int tx, ty;
   if (!smk_tile_of_block(P, blockIdx.x, tx, ty)) return;
@@ -25,7 +26,7 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
   const float px = __fmaf_rn((float)i + 0.5f, rc.pxs, rc.pxl);
   const float py = __fmaf_rn((float)j + 0.5f, rc.pys, rc.pyl);
   float A[3], B[3], tauA, dtau;  // (tauA, dtau: frames with shadows only, see smk_ray_AB)
-  const bool ray_ok = smk_ray_AB(P, px, py, A, B, tauA, dtau);
+  const bool ray_ok = smk_ray_AB_t<SHD>(P, px, py, A, B, tauA, dtau);
 
   // conservative plane range [m0,m1] from a slab test (+-2 planes of slack); the exact
   // per-sample inside test below is what decides membership
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
     if (!in) continue;
     // free clip plane (glClipPlane semantics, NV20VolRen3D.cpp:346-357): fragments on its negative side do not exist
     if (P.cplane_on && !(__fmaf_rn(p0, P.cplane[0], __fmaf_rn(p1, P.cplane[1], __fmaf_rn(p2, P.cplane[2], P.cplane[3]))) >= 0.0f)) continue;
-    if (P.sh.on && !smk_tau_ok(tauA, dtau, m)) continue;  // (half-angle slices: a sample behind the eye does not exist)
+    if (SHD && !smk_tau_ok(tauA, dtau, m)) continue;  // (half-angle slices: a sample behind the eye does not exist)
     const float q0 = p0, q1 = p1, q2 = p2;  // (the sample's own position: where its light-buffer lookup is made)
 
     if (P.pert_on) {
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void smk_k_gather(const RenderParams P) {
     // frames with shadows: the light-buffer colour over the sample, as the slices nearer the light left it (smk_shadow.hip)
     float shadow[3];
     const float *shp = nullptr;
-    if (TF != 0 && P.sh.on) {
+    if (TF != 0 && SHD) {
       smk_shadow_term(P, m, q0, q1, q2, shadow);
       shp = shadow;
     }
@@ -261,14 +262,22 @@ hipError_t smk_launch_count_inside(const RenderParams &P, unsigned long long *d_
   return hipGetLastError();
 }
 
-template <int DT, int TF, int SH>
+template <int DT, int TF, int SH, bool SHD = false>
 static hipError_t launch(const RenderParams &P, hipStream_t s) {
   dim3 grid(8 * P.tiles_per_xcd), block(256);
-  hipLaunchKernelGGL((smk_k_gather<DT, TF, SH>), grid, block, 0, s, P);
+  hipLaunchKernelGGL((smk_k_gather<DT, TF, SH, SHD>), grid, block, 0, s, P);
   return hipGetLastError();
 }
 
 hipError_t smk_launch_gather(const RenderParams &P, int dtype, int tf_mode, int shade_kind, hipStream_t s) {
+  if (P.sh.on) {  // the eye pass of a frame with shadows: 2-D / 3-D table, R8k shading or none
+#define CASE(D, T, S) \
+  if (dtype == D && tf_mode == T && shade_kind == S) return launch<D, T, S, true>(P, s);
+    CASE(0, 1, 0) CASE(0, 1, 1) CASE(0, 2, 0) CASE(0, 2, 1)
+    CASE(1, 1, 0) CASE(1, 1, 1) CASE(1, 2, 0) CASE(1, 2, 1)
+#undef CASE
+    return hipErrorInvalidValue;
+  }
 #define CASE(D, T, S) \
   if (dtype == D && tf_mode == T && shade_kind == S) return launch<D, T, S>(P, s);
   CASE(0, 0, 0) CASE(0, 1, 0) CASE(0, 1, 1) CASE(0, 1, 2) CASE(0, 2, 0) CASE(0, 2, 1) CASE(0, 2, 2)

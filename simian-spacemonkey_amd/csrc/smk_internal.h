@@ -29,7 +29,8 @@ struct SmkShadowRays {
   float numA, dB;
   int k0, dk, LB;
   float Xm[4], Ym[4], Wm[4], lscale, lbias;
-  const float4 *hist;  // [nslices + 1][LB][LB]
+  const float4 *hist;  // [nslices + 1] buffers of [LB][LB] texels, `hstride` texels apart
+  long long hstride;   // (LB * LB + a pad: buffers a power of two apart would meet in the same memory channels)
 };
 
 // Everything a render kernel needs, passed by value as the kernarg (wave-uniform => SGPRs).
@@ -333,7 +334,8 @@ hipError_t smk_launch_count_inside(const RenderParams &P, unsigned long long *d_
 // one launch per slice (smk_shadow.hip); L0 cleared by the caller
 hipError_t smk_launch_shadow(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, int shade_kind,
                              float4 *L0, float4 *L1, unsigned *barrier /* one device word for the fused launch's grid barrier, or null */, hipStream_t s);
-hipError_t smk_launch_shadow_march(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, float4 *hist, hipStream_t s);
+hipError_t smk_launch_shadow_march(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, float4 *hist, long long hstride,
+                                   hipStream_t s);
 // returns hipErrorNotSupported (and *why) when the frame must use the gather kernel
 hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kind, int opt_T, int opt_tile, int forced,
                            const void *vox_native, const void *vox_xmajor, SlabAux *aux, const char **why,

@@ -357,16 +357,26 @@ __device__ __forceinline__ bool shadow_tile_of_block(int bid, int ntiles, int &t
   return k < per && tile < ntiles;
 }
 
-// the light march: one thread per texel, every slice; hist[k] = the light buffer after slices 1..k (hist[0] = cleared)
+// The light march: hist[k] = the light buffer after slices 1..k (hist[0] = cleared).  A texel's recurrence over the slices
+// is sequential, but what it blends -- the classified sample of its light ray in each slice -- is not: a wave takes 8 texels
+// x 8 CONSECUTIVE slices (lane = texel + 8 * slice), fetches and classifies its 64 samples at once (one chain of dependent
+// gathers per 8 slices instead of one per slice: a thread per texel walking 512 slices took 1.8 ms for a 512^2 buffer), then
+// lays the 8 slices' samples over the running value in order -- 8 short steps on values passed between lanes, every lane of a
+// texel computing the same running value, lane s keeping it as slice s leaves it -- and stores 8 buffers' worth.  The same
+// operations in the same order per texel as a launch per slice: bit-identical light buffers.
 template <int DT, int TF>
-__global__ __launch_bounds__(256) void smk_k_shadow_light_march(const RenderParams P, const ShadowSlice Q, float4 *hist) {
+__global__ __launch_bounds__(256) void smk_k_shadow_light_march(const RenderParams P, const ShadowSlice Q, float4 *hist, long long hstride) {
   const smk_shadowcoef &sc = Q.sc;
+  // blocks of 8 x 4 texels (a wave = 8 texels of one row), dealt to the XCDs in contiguous runs
+  // (8 waves side by side -- 64 x 1 texels, a block's stores into one buffer one run of memory -- measured slower: 1.25 vs 1.0 ms)
+  const int bx = (sc.LB + 7) >> 3, by = (sc.LB + 3) >> 2;
   int tile;
-  if (!shadow_tile_of_block((int)blockIdx.x, Q.light_bx * Q.light_bx, tile)) return;
+  if (!shadow_tile_of_block((int)blockIdx.x, bx * by, tile)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int x = (tile % Q.light_bx) * 16 + (wave & 1) * 8 + (lane & 7), y = (tile / Q.light_bx) * 16 + (wave >> 1) * 8 + (lane >> 3);
-  if (x >= sc.LB || y >= sc.LB) return;
-  const size_t nl = (size_t)sc.LB * sc.LB, o = (size_t)y * sc.LB + x;
+  const int t = lane & 7, sl = lane >> 3;
+  const int x = (tile % bx) * 8 + t, y = (tile / bx) * 4 + wave;
+  const bool live = x < sc.LB && y < sc.LB;
+  const size_t nl = (size_t)hstride, o = (size_t)y * sc.LB + x;  // (buffers `hstride` texels apart)
   const float a = __fmaf_rn((float)x + 0.5f, sc.las, sc.lal), bb = __fmaf_rn((float)y + 0.5f, sc.las, sc.lal);
   const float nG = __fmaf_rn(a, sc.nGx, __fmaf_rn(bb, sc.nGy, sc.nGc));
   float G[3];
@@ -374,52 +384,106 @@ __global__ __launch_bounds__(256) void smk_k_shadow_light_march(const RenderPara
   for (int q = 0; q < 3; ++q) G[q] = __fmaf_rn(a, sc.Gx[q], __fmaf_rn(bb, sc.Gy[q], sc.Gc[q]));
   int k0, k1;
   shadow_k_range(P, sc.lnum0, sc.ldnum, nG, G, sc.Lc, sc.nslices, k0, k1);
+  if (!live) k1 = 0;
   float4 L = make_float4(0.f, 0.f, 0.f, 0.f);
-  hist[o] = L;
-  for (int k = 1; k <= sc.nslices; ++k) {
-    if (k >= k0 && k <= k1) {
-      const float w = __fdiv_rn(__fmaf_rn((float)k, sc.ldnum, sc.lnum0), nG);
-      bool in = w > 0.0f && !isinf(w);
-      float p[3];
+  if (live && sl == 0) hist[o] = L;
+  // where this lane's sample of slice k is, and -- requested one turn of the loop ahead, so that the first of the turn's
+  // dependent round trips is over when the turn begins -- the flag of its brick (shadow_brick_empty's test)
+  float p[3] = {0.f, 0.f, 0.f};
+  auto place = [&](int k) -> bool {
+    if (!(k >= k0 && k <= k1 && k <= sc.nslices)) return false;
+    const float w = __fdiv_rn(__fmaf_rn((float)k, sc.ldnum, sc.lnum0), nG);
+    bool in = w > 0.0f && !isinf(w);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        p[q] = __fmaf_rn(w, G[q], sc.Lc[q]);
-        in = in && p[q] >= -0.5f && p[q] <= (float)P.N[q] - 0.5f;
-      }
-      if (in && !shadow_brick_empty(P, p[0], p[1], p[2])) {
+    for (int q = 0; q < 3; ++q) {
+      p[q] = __fmaf_rn(w, G[q], sc.Lc[q]);
+      in = in && p[q] >= -0.5f && p[q] <= (float)P.N[q] - 0.5f;
+    }
+    return in;
+  };
+  auto flag_of = [&](bool in) -> unsigned char {
+    if (!in) return 0;
+    if (P.bricks == nullptr) return 1;
+    int x0, x1, y0, y1, z0, z1;
+    float fx, fy, fz;
+    smk_lin_clamp(p[0], P.N[0], x0, x1, fx);
+    smk_lin_clamp(p[1], P.N[1], y0, y1, fy);
+    smk_lin_clamp(p[2], P.N[2], z0, z1, fz);
+    return P.bricks[((size_t)(z0 >> SMK_BRICK_LOG2) * P.nbr[1] + (size_t)(y0 >> SMK_BRICK_LOG2)) * P.nbr[0] + (size_t)(x0 >> SMK_BRICK_LOG2)];
+  };
+  // the slices some texel of this wave can have a sample in: before them every buffer is the cleared one, behind them the
+  // last one -- those turns of the loop only store
+  int klo = k1 >= k0 ? k0 : 0x7fffffff, khi = k1 >= k0 ? k1 : -0x7fffffff;
+  for (int off = 32; off > 0; off >>= 1) {
+    klo = min(klo, __shfl_xor(klo, off));
+    khi = max(khi, __shfl_xor(khi, off));
+  }
+  const int kb_first = klo > khi ? sc.nslices + 1 : 1 + ((klo - 1) & ~7);  // first turn with work (turns start at 1 + 8 n)
+  for (int kb = 1; kb < kb_first && kb <= sc.nslices; kb += 8)
+    if (live && kb + sl <= sc.nslices) hist[(size_t)(kb + sl) * nl + o] = L;
+  // Four turns' worth (32 slices) of positions and brick flags at a time: the flag loads are in flight together -- one round
+  // trip per 32 slices where a turn of its own costs one per 8 (the march is bound by such round trips: 1.0 -> x.xx ms)
+  int kb = kb_first;
+  for (; kb <= sc.nslices && kb <= khi; kb += 32) {
+    float pu[4][3];
+    unsigned char fl[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      fl[u] = flag_of(place(kb + 8 * u + sl));
+      pu[u][0] = p[0]; pu[u][1] = p[1]; pu[u][2] = p[2];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = kb + 8 * u + sl;
+      float4 col = make_float4(0.f, 0.f, 0.f, 0.f);  // this lane's sample: saturated colour and alpha, alpha 0 = nothing to lay over
+      if (fl[u]) {
         float ch0, ch1, ch2, ch3, n0, n1, n2;
-        shadow_fetch<DT, TF, false>(P, p[0], p[1], p[2], ch0, ch1, ch2, ch3, n0, n1, n2);
-        float4 col;
-        if (shadow_maybe_visible<TF>(P, ch0, ch1) && smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, col)) {
-          const float al = col.w;  // (R8kVolRen3D.cpp:3150-3165, as shadow_light_texel)
-          L.x = smk_sat(__fmaf_rn(al, smk_sat(col.x) - L.x, L.x));
-          L.y = smk_sat(__fmaf_rn(al, smk_sat(col.y) - L.y, L.y));
-          L.z = smk_sat(__fmaf_rn(al, smk_sat(col.z) - L.z, L.z));
-          L.w = smk_sat(__fmaf_rn(1.0f - al, L.w, al));
+        shadow_fetch<DT, TF, false>(P, pu[u][0], pu[u][1], pu[u][2], ch0, ch1, ch2, ch3, n0, n1, n2);
+        float4 cc;
+        if (shadow_maybe_visible<TF>(P, ch0, ch1) && smk_classify<DT, TF>(P, ch0, ch1, ch2, ch3, cc))
+          col = make_float4(smk_sat(cc.x), smk_sat(cc.y), smk_sat(cc.z), cc.w);
+      }
+      float4 mine = L;  // the running value as slice k leaves it (lanes of slices nobody lays anything over: unchanged)
+      if (__any(col.w != 0.0f)) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const int src = t + 8 * s;
+          const float al = __shfl(col.w, src), cx = __shfl(col.x, src), cy = __shfl(col.y, src), cz = __shfl(col.z, src);  // (every lane active)
+          // LERP r0.a, r0, r5 (saturated); alpha = sat((1 - a) r5.a + a)   (R8kVolRen3D.cpp:3150-3165, as shadow_light_texel)
+          if (al != 0.0f) {
+            L.x = smk_sat(__fmaf_rn(al, cx - L.x, L.x));
+            L.y = smk_sat(__fmaf_rn(al, cy - L.y, L.y));
+            L.z = smk_sat(__fmaf_rn(al, cz - L.z, L.z));
+            L.w = smk_sat(__fmaf_rn(1.0f - al, L.w, al));
+          }
+          if (s == sl) mine = L;
         }
       }
+      if (live && k <= sc.nslices) hist[(size_t)k * nl + o] = mine;
     }
-    hist[(size_t)k * nl + o] = L;
   }
+  for (; kb <= sc.nslices; kb += 8)
+    if (live && kb + sl <= sc.nslices) hist[(size_t)(kb + sl) * nl + o] = L;
 }
 
 template <int DT, int TF>
-static hipError_t run_march(const RenderParams &P, ShadowSlice Q, float4 *hist, hipStream_t s) {
+static hipError_t run_march(const RenderParams &P, ShadowSlice Q, float4 *hist, long long hstride, hipStream_t s) {
   const smk_shadowcoef &sc = Q.sc;
-  Q.light_bx = (sc.LB + 15) / 16;
-  const int lblocks = 8 * ((Q.light_bx * Q.light_bx + 7) / 8);
-  hipLaunchKernelGGL((smk_k_shadow_light_march<DT, TF>), dim3(lblocks), dim3(256), 0, s, P, Q, hist);
+  const int tiles = ((sc.LB + 7) / 8) * ((sc.LB + 3) / 4);
+  const int lblocks = 8 * ((tiles + 7) / 8);
+  hipLaunchKernelGGL((smk_k_shadow_light_march<DT, TF>), dim3(lblocks), dim3(256), 0, s, P, Q, hist, hstride);
   return hipGetLastError();
 }
 
-// The light march alone: hist = [nslices + 1][LB][LB] texels, hist[k] = the light buffer after slices 1..k.  The eye pass is
+// The light march alone: hist = nslices + 1 buffers of [LB][LB] texels, `hstride` texels apart; hist[k] = the light buffer after slices 1..k.  The eye pass is
 // then an ordinary frame of the ray-marchers over the half-angle slices (P.sh, smk_api.hip).
-hipError_t smk_launch_shadow_march(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, float4 *hist, hipStream_t s) {
+hipError_t smk_launch_shadow_march(const RenderParams &P, const smk_shadowcoef &sc, int dtype, int tf_mode, float4 *hist, long long hstride,
+                                   hipStream_t s) {
   ShadowSlice Q;
   memset(&Q, 0, sizeof Q);
   Q.sc = sc;
 #define CASE(D, T) \
-  if (dtype == D && tf_mode == T) return run_march<D, T>(P, Q, hist, s);
+  if (dtype == D && tf_mode == T) return run_march<D, T>(P, Q, hist, hstride, s);
   CASE(0, 1) CASE(0, 2) CASE(1, 1) CASE(1, 2)
 #undef CASE
   return hipErrorNotSupported;

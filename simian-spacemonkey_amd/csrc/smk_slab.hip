@@ -242,7 +242,9 @@ __device__ __forceinline__ float slab_tex_chan(const SlabTexel4 &x, int k) {
 // table (TFWidgetRen.cpp:779-845; BASELINE configs 4/5)
 // (BR: the instance knows about brick flags -- EMPTY LAYERS; frames without flags run instances that carry none of it:
 //  the run-time test alone, three per loop turn, cost them 12 % in scalar registers spilled)
-template <int DT, int SH, int PERM, int NW, int NL, bool DIAG, int TF = 1, bool BR = true>
+// (SHD: the frame's planes are the half-angle slices of a frame with shadows -- SmkShadowRays; the eye pass of smk_shadow.hip.
+//  Compile-time: the instances live in smk_slab_shadow.hip, SLAB_PART 2)
+template <int DT, int SH, int PERM, int NW, int NL, bool DIAG, int TF = 1, bool BR = true, bool SHD = false>
 #ifndef SLAB_BIG_WAVES
 #define SLAB_BIG_WAVES 12  // workgroups of more waves than this are "big": one per CU
 #endif
@@ -323,7 +325,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   const float px = __fmaf_rn((float)i + 0.5f, rc.pxs, rc.pxl);
   const float py = __fmaf_rn((float)j + 0.5f, rc.pys, rc.pyl);
   float A[3], B[3], tauA, dtau;  // (tauA, dtau: frames with shadows only -- the ray parameter of plane q is fma(q, dtau, tauA), smk_ray_AB)
-  const bool ray_ok = smk_ray_AB(P, px, py, A, B, tauA, dtau);
+  const bool ray_ok = smk_ray_AB_t<SHD>(P, px, py, A, B, tauA, dtau);
   // conservative plane range (identical to the gather kernel)
   float tenter = 0.0f, texit = (float)(rc.nplanes - 1);
   bool empty = rc.nplanes <= 0 || !live || !ray_ok;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
   }
   // Frames with shadows: a sample exists where its ray parameter fma(q, dtau, tauA) is positive -- monotone in q like the clip
   // plane's value, folded into the range the same way.
-  if (P.sh.on && ray_ok) {
+  if (SHD && ray_ok) {
     if (fabsf(dtau) > 1e-30f) {
       const float tz = -tauA / dtau;
       if (dtau > 0.0f) tenter = fmaxf(tenter, tz - 2.0f);
@@ -384,7 +386,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
                  (int)(smk_clampf(p2, P.lo[2], P.hin[2]) == p2)) != 0;
       // (the gather kernel's own fma chain for the plane: the same samples pass, bit for bit)
       if (P.cplane_on) in = in && __fmaf_rn(p0, P.cplane[0], __fmaf_rn(p1, P.cplane[1], __fmaf_rn(p2, P.cplane[2], P.cplane[3]))) >= 0.0f;
-      if (P.sh.on) in = in && smk_tau_ok(tauA, dtau, q);
+      if (SHD) in = in && smk_tau_ok(tauA, dtau, q);
       return in;
     };
     int mf = m1 + 1, ml = m - 1;
@@ -521,7 +523,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
       int cj = min(ty * Q.th + ((c & 2) ? Q.th - 1 : 0), P.H - 1);
       float cx = __fmaf_rn((float)ci + 0.5f, rc.pxs, rc.pxl), cy = __fmaf_rn((float)cj + 0.5f, rc.pys, rc.pyl);
       float cta, cdt;
-      (void)smk_ray_AB(P, cx, cy, cA[c], cB[c], cta, cdt);  // (the launcher declines frames whose rays can run parallel to the slices)
+      (void)smk_ray_AB_t<SHD>(P, cx, cy, cA[c], cB[c], cta, cdt);  // (the launcher declines frames whose rays can run parallel to the slices)
     }
     if (Q.use_ah)
       for (int e = tid; e < P.sv; e += NTH) ah[e] = smk_ub(P.tf_h[e], 3);
@@ -1359,7 +1361,7 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
             // (smk_shadow.hip; the sample's own position: the gather kernel's fma chain)
             float shadow[3];
             const float *shp = nullptr;
-            if (TF != 0 && P.sh.on) {
+            if (TF != 0 && SHD) {
               const float mf = (float)m;
               smk_shadow_term(P, m, __fmaf_rn(mf, B[0], A[0]), __fmaf_rn(mf, B[1], A[1]), __fmaf_rn(mf, B[2], A[2]), shadow);
               shp = shadow;
@@ -1494,8 +1496,9 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 9) ? 6 : ((NW + NL) =
 
 // ------------------------------------------------------------------------------- host side
 
-// This file is compiled twice (build time: the instances are most of it): as itself -- host side + the byte-voxel
-// instances -- and through smk_slab_f32.hip (SLAB_PART 1) -- the float-voxel instances alone.
+// This file is compiled three times (build time: the instances are most of it): as itself -- host side + the byte-voxel
+// instances --, through smk_slab_f32.hip (SLAB_PART 1) -- the float-voxel instances alone -- and through smk_slab_shadow.hip
+// (SLAB_PART 2) -- the instances of the eye pass of frames with shadows.
 #ifndef SLAB_PART
 #define SLAB_PART 0
 #endif
@@ -1728,9 +1731,9 @@ bool slab_bundle_slice_range_exact(const RenderParams &P, double fx0, double fy0
 }  // namespace
 #endif  // SLAB_PART == 0
 
-template <int DT, int SH, int PERM, int NW, int NL, bool DIAG, int TF = 1, bool BR = true>
+template <int DT, int SH, int PERM, int NW, int NL, bool DIAG, int TF = 1, bool BR = true, bool SHD = false>
 static hipError_t launch_slab(const RenderParams &P, const SlabParams &Q, size_t lds, int nblocks, hipStream_t s) {
-  auto k = smk_k_slab<DT, SH, PERM, NW, NL, DIAG, TF, BR>;
+  auto k = smk_k_slab<DT, SH, PERM, NW, NL, DIAG, TF, BR, SHD>;
   static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -1750,6 +1753,35 @@ hipError_t smk_slab_dispatch_u8(const RenderParams &P, const SlabParams &Q, int 
                                 int nblocks, const char **why, hipStream_t s);
 hipError_t smk_slab_dispatch_f32(const RenderParams &P, const SlabParams &Q, int tf_mode, int shade_kind, int nw, int nl, bool diag, size_t lds,
                                  int nblocks, const char **why, hipStream_t s);
+// ... and one for the eye pass of frames with shadows (SHD instances: 2-D / 3-D table, R8k shading or none, both voxel types)
+hipError_t smk_slab_dispatch_shadow(const RenderParams &P, const SlabParams &Q, int dtype, int tf_mode, int shade_kind, int nw, int nl, size_t lds,
+                                    int nblocks, const char **why, hipStream_t s);
+#if SLAB_PART == 2
+hipError_t smk_slab_dispatch_shadow(const RenderParams &P, const SlabParams &Q, int dtype, int tf_mode, int shade_kind, int nw, int nl, size_t lds,
+                                    int nblocks, const char **why, hipStream_t s) {
+#define GO(D, S, R, N, L)                                                                                  \
+  if (dtype == D && shade_kind == S && Q.perm == R && nw == N && nl == L) {                              \
+    if (tf_mode == 2) {                                                                                  \
+      if (Q.bricks) return (launch_slab<D, S, R, N, L, false, 2, true, true>(P, Q, lds, nblocks, s));    \
+      return (launch_slab<D, S, R, N, L, false, 2, false, true>(P, Q, lds, nblocks, s));                 \
+    }                                                                                                    \
+    if (tf_mode == 1) {                                                                                  \
+      if (Q.bricks) return (launch_slab<D, S, R, N, L, false, 1, true, true>(P, Q, lds, nblocks, s));    \
+      return (launch_slab<D, S, R, N, L, false, 1, false, true>(P, Q, lds, nblocks, s));                 \
+    }                                                                                                    \
+    *why = "shadows need a 2-D or 3-D table";                                                            \
+    return hipErrorNotSupported;                                                                         \
+  }
+#define GO_NW(D, S, R) GO(D, S, R, 8, 2) GO(D, S, R, 10, 2) GO(D, S, R, 12, 4)
+#define GO_R(D, S) GO_NW(D, S, 0) GO_NW(D, S, 1) GO_NW(D, S, 2)
+  GO_R(0, 0) GO_R(0, 1) GO_R(1, 0) GO_R(1, 1)
+#undef GO_R
+#undef GO_NW
+#undef GO
+  *why = "no shadow instance for this configuration";
+  return hipErrorNotSupported;
+}
+#else
 #if SLAB_PART == 0
 hipError_t smk_slab_dispatch_u8(const RenderParams &P, const SlabParams &Q, int tf_mode, int shade_kind, int nw, int nl, bool diag, size_t lds,
                                 int nblocks, const char **why, hipStream_t s) {
@@ -1806,6 +1838,7 @@ hipError_t smk_slab_dispatch_f32(const RenderParams &P, const SlabParams &Q, int
   *why = "no kernel instance for this tile size";
   return hipErrorNotSupported;
 }
+#endif  // SLAB_PART != 2
 
 #if SLAB_PART == 0
 hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kind, int opt_T, int opt_tile, int forced,
@@ -2595,8 +2628,9 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
       aux->ticks_pending_n = ticks_n_now;
       return hipSuccess;
     };
-    return after_launch(dtype == 0 ? smk_slab_dispatch_u8(P, Q, tf_mode, shade_kind, nw, nl, diag, lds, nblocks, why, s)
-                                   : smk_slab_dispatch_f32(P, Q, tf_mode, shade_kind, nw, nl, diag, lds, nblocks, why, s));
+    return after_launch(P.sh.on     ? smk_slab_dispatch_shadow(P, Q, dtype, tf_mode, shade_kind, nw, nl, lds, nblocks, why, s)
+                        : dtype == 0 ? smk_slab_dispatch_u8(P, Q, tf_mode, shade_kind, nw, nl, diag, lds, nblocks, why, s)
+                                     : smk_slab_dispatch_f32(P, Q, tf_mode, shade_kind, nw, nl, diag, lds, nblocks, why, s));
   }
   }  // pass
   (void)forced;
