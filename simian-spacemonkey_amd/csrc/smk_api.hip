@@ -1850,7 +1850,11 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
         c->tune_sig = sig;
         c->tune_state = 0;
       }
-      if (c->tune_state == 4) {  // both timed trials issued: decide once their events have completed
+      // Trial frames of a new configuration: SMK_TUNE_SETTLE untimed slice-ring frames -- its schedule and depth cuts come
+      // from the workgroup times of earlier frames, so each waits for the one before it (a one-time stall; without it, and
+      // with a single untimed frame, the timed trial was the first frame with cuts, 1.14 ms on a 1/8 shard that settles at
+      // 0.15, and auto mode kept the 0.69 ms gather kernel for the shard) --, one untimed gather frame, then the timed pair.
+      if (c->tune_state == SMK_TUNE_SETTLE + 3) {  // both timed trials issued: decide once their events have completed
         float ms_s = 0, ms_g = 0;
         // (a host that enqueues frames far ahead of the GPU would recycle the trials' event pairs -- the ring holds the
         //  last 64 frames -- before they complete, and the comparison would then be between two later frames of the
@@ -1865,8 +1869,9 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
         }  // else: keep the slice-ring kernel for this frame and ask again
         (void)hipGetLastError();
       } else {
-        trial = c->tune_state;  // 0,1: untimed first launches (one-time set-up), 2,3: the timed pair
-        try_slab = (trial & 1) == 0;
+        trial = c->tune_state;
+        try_slab = trial != SMK_TUNE_SETTLE && trial != SMK_TUNE_SETTLE + 2;
+        if (try_slab && trial > 0) (void)hipStreamSynchronize(s);  // (the previous settle frame's workgroup times are back)
       }
     }
   }
@@ -1935,8 +1940,8 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
   }
   HIPCHK(c, hipEventRecord(c->ev1, s));
   if (trial >= 0) {
-    if (trial >= 2) {
-      c->tune_slot[trial - 2] = slot;
+    if (trial >= SMK_TUNE_SETTLE + 1) {
+      c->tune_slot[trial - (SMK_TUNE_SETTLE + 1)] = slot;
       c->tune_tcount = c->tcount;
     }
     c->tune_state = trial + 1;

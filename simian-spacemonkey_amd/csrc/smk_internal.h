@@ -14,6 +14,7 @@
 #define SMK_TIMING_RING 64
 #define SMK_BRICK_LOG2 3   // bricks of 8x8x8 cells (smk_bricks.hip)
 #define SMK_SHADOW_BOX_EPS 0.0009765625f  // voxels: frames with shadows test an eye sample against the box widened by this (smk_api.hip)
+#define SMK_TUNE_SETTLE 6  // auto mode: untimed slice-ring frames before a new configuration's timed trial (smk_api.hip)
 #define SMK_STATUS_RING 8  // frames whose slice-ring status stays readable (smk_frame_failed)
 
 // Eye rays of a frame with shadows (half-angle slicing, smk_shadow.hip).  The slice planes are not perpendicular to the

@@ -2127,7 +2127,10 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     if ((nw + nl) <= SLAB_BIG_WAVES && Q.groups * Q.rpg <= Q.Dv) Q.wv = Q.groups * Q.rpg;
     Q.chunks = Q.groups * Q.per;
     if (pass == 0) {  // probing: DMA instructions per ray
-      const double score = (double)Q.chunks / (nw * 64);
+      // (the ten-wave shape leaves four of a CU's wave slots idle: with the brick flags on it measures 0.83 ms on the cfg 3
+      //  frame where the twelve-wave shapes take 0.59-0.61, although it needs the fewest DMA instructions per ray at some
+      //  poses -- a camera turning through such a pose got 0.79 ms frames for 0.63.  It has to win by 40 % now.)
+      const double score = (double)Q.chunks / (nw * 64) * (nw + nl < 12 ? 1.4 : 1.0);
       if (score < best_score) { best_score = score; best = ci; }
       continue;
     }
@@ -2506,7 +2509,9 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
       aux->nsplit_last = nsplit;
       aux->nblocks_last = nblocks;
       if (maxseg > 1) {
-        const size_t need = (size_t)(maxseg - 1) * P.W * P.H * 16;
+        // (room for the largest piece count at once: growing the buffer when a tile's count rises is a hipFree + hipMalloc,
+        //  ~1 ms in the middle of a session -- 7 partial frames of a 1024^2 viewport are 112 MB of 288 GB)
+        const size_t need = (size_t)(8 - 1) * P.W * P.H * 16;
         if (need > aux->seg_cap) {
           if (aux->d_seg) (void)hipFree(aux->d_seg);
           aux->d_seg = nullptr;
@@ -2540,13 +2545,16 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
             aux->h_order[k] = nullptr;
           }
           aux->order_cap = 0;
-          hipError_t e = hipMalloc((void **)&aux->d_order, order.size() * sizeof(int2));
+          // (with headroom: the table grows by a few entries whenever a tile's piece count rises, and every regrowth is a
+          //  device free + allocation and four pinned ones -- a 1 ms hiccup every few dozen frames on a shard)
+          const size_t cap = order.size() * 2 + 1024;
+          hipError_t e = hipMalloc((void **)&aux->d_order, cap * sizeof(int2));
           if (e != hipSuccess) return e;
           for (int k = 0; k < 4; ++k) {
-            e = hipHostMalloc((void **)&aux->h_order[k], order.size() * sizeof(int2), hipHostMallocDefault);
+            e = hipHostMalloc((void **)&aux->h_order[k], cap * sizeof(int2), hipHostMallocDefault);
             if (e != hipSuccess) return e;
           }
-          aux->order_cap = (int)order.size();
+          aux->order_cap = (int)cap;
         }
         // pinned staging + a copy ON THE LAUNCH STREAM: a copy from pageable memory is not
         // stream-ordered against the kernel that follows (seen as wrong tiles when several

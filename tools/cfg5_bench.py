@@ -42,7 +42,10 @@ def main():
     r.set_camera(mv, bench.FRUSTUM, (1.0, 20.0), size, size)
     r.set_sampling(0.0, planes, 1.0, 1)
     r.set_shading("r8k", bench.LIGHT, bench.EYE, bench.AT, [float(v) for v in xform.T.reshape(-1)], bench.INTENS)
-    r.set_perturb(O.noise_tex(32), (.02, .01, 0, 0), (.2, 2.1, 4.5, 8.7))
+    full = "full" in sys.argv[1:]   # SURVEY 8(d)'s weights (.2, .1); default: a tenth of them
+    if full:
+        sys.argv.remove("full")
+    r.set_perturb(O.noise_tex(32), (.2, .1, 0, 0) if full else (.02, .01, 0, 0), (.2, 2.1, 4.5, 8.7))
     out = torch.zeros((size * size, 4), dtype=torch.float32, device="cuda")
     base = None
     for var in [""] + sys.argv[1:]:

@@ -24,6 +24,8 @@ def main():
     del vghf, nrm
     bench.configure(r, "cfg3", n, 1024, 512)
     r.set_option("kernel", int(os.environ.get("SMK_KERNEL", "0")))
+    if os.environ.get("SMK_TILE"):    # (developer: force a slice-ring workgroup shape, option "tile")
+        r.set_option("tile", int(os.environ["SMK_TILE"]))
     frame = torch.zeros((1024 * 1024, 4), dtype=torch.float32, device="cuda")
     st = torch.cuda.current_stream().cuda_stream
 
