@@ -141,7 +141,12 @@ int smk_set_perturb(smk_ctx *ctx, const unsigned char *noise_rgba, int n, const 
  * gluvv.light.gShadowQual or iShadowQual: the light buffer has ceil(quality * buffer_px)^2 texels.
  * Applies to 2-D / 3-D classification with no or R8k shading on an unsharded context; other
  * configurations make smk_render fail with the reason.  The blend order follows the light (under when
- * the slices run away from the eye, over otherwise), smk_set_blend is not consulted. */
+ * the slices run away from the eye, over otherwise), smk_set_blend is not consulted.
+ * How it is rendered: a light-buffer texel depends on itself alone from slice to slice, so the light pass is
+ * ONE march per texel that keeps every slice's buffer (nslices + 1 buffers in device memory), and the eye pass is an
+ * ordinary frame of the ray-marchers over the half-angle slices that looks each sample's slice up -- two launches instead
+ * of one per slice.  Option "shadow_march" 0 (or a history that does not fit a quarter of the free device memory) renders
+ * a launch per slice as the reference draws them: the same samples, bit-identical light buffers. */
 int smk_set_shadow(smk_ctx *ctx, int on, int buffer_px, float quality);
 /* replaces the glBlendFunc / glBlendEquationEXT state of the slice loop (VolumeRenderer.cpp:589-590,
  * NV20VolRen3D.cpp:158-163, 930; R8kVolRen3D.cpp:1436-1449).  Default: front to back.  The two
@@ -262,10 +267,14 @@ typedef struct {
   float tau0, dtau, zmin, zmax, dis;
 } smk_raycoef;
 int smk_get_raycoef(smk_ctx *ctx, smk_raycoef *out);
-/* sample placement of a frame with shadows: slice k = 1..nslices; an eye ray's sample is fma(tau, D, Ec)
- * with D_a = fma(px, Dx_a, fma(py, Dy_a, Dc_a)), tau = fma(k, dnum, num0) / fma(px, nDx, fma(py, nDy, nDc));
- * a light-buffer texel's likewise from (las, lal, Lc, G*, nG*, lnum0, ldnum); X/Y/Wm map a voxel coordinate
- * to light space, its light-buffer position is fma(x'/w, lscale, lbias) (DESIGN.md "Shadows") */
+/* sample placement of a frame with shadows: slice k = 1..nslices in the light's order.  A light-buffer texel's sample is
+ * fma(w, G, Lc) with G_a = fma(a, Gx_a, fma(b, Gy_a, Gc_a)), (a, b) = fma(texel + .5, las, lal),
+ * w = fma(k, ldnum, lnum0) / fma(a, nGx, fma(b, nGy, nGc)).  An eye ray's planes are counted FROM THE EYE, m = k - 1 when the
+ * slices run away from the viewer (front_to_back), nslices - k otherwise: with D_a = fma(px, Dx_a, fma(py, Dy_a, Dc_a)),
+ * nD = fma(px, nDx, fma(py, nDy, nDc)), numA = plane 0's numerator (fma(1, dnum, num0) or fma(nslices, dnum, num0)) and
+ * dB = +-dnum:  tauA = numA / nD, dtau = dB / nD, A_a = fma(tauA, D_a, Ec_a), B_a = dtau * D_a, sample = fma(m, B, A), which
+ * exists where fma(m, dtau, tauA) is positive and finite and lies within 2^-10 voxels of the volume's box.  X/Y/Wm map a
+ * voxel coordinate to light space, its light-buffer position is fma(x'/w, lscale, lbias) (DESIGN.md "Shadows") */
 typedef struct {
   float pxs, pxl, pys, pyl;
   float Ec[3], Dc[3], Dx[3], Dy[3];
@@ -304,6 +313,8 @@ int smk_get_brick_flags(smk_ctx *ctx, unsigned char *flags_out, int *nb_out, int
  *   "bricks"   [1] empty-space skipping: 8x8x8-cell bricks in which no sample can be visible under the current
  *              table are neither streamed nor sampled (the skipped samples are exactly transparent: frames are
  *              bit-identical with 0 and 1); 0 = every sample is fetched and classified
+ *   "shadow_march" [1] frames with shadows as two marches (light-buffer texels, then eye pixels on the ray-marchers);
+ *              0 = a launch per slice
  *   developer knobs: "tile" (slice-ring workgroup shape id), "slab_T" (band wait + 1), "slab_fly"
  *   (slices a loader keeps in flight), "slab_ns" (cap on the ring's slots), "lockstep" (bit 0 gather lockstep; bits 1..6 slice-ring
  *   diagnostics, see tools/kbench.py), "wave_w"/"blk_w" (gather tile shape), "inject_slab_status"
@@ -313,8 +324,9 @@ int smk_set_option(smk_ctx *ctx, const char *key, int value);
  * membership test for every plane of every ray, nothing fetched.  SURVEY 8(d)'s "in-volume sample count", to be read
  * beside the nominal width x height x planes.  Synchronises. */
 int smk_count_samples(smk_ctx *ctx, double *in_volume);
-/* last frame: which kernel ran (1 gather, 2 slice-ring, 3 the per-slice shadow passes), its HIP-event time in ms,
- * algorithmic bytes */
+/* last frame: which kernel ran (1 gather, 2 slice-ring, 3 the per-slice shadow passes of option shadow_march 0, 4 column-
+ * stream; a frame with shadows reports the kernel of its eye pass, its time covers the light march too), its HIP-event time
+ * in ms, algorithmic bytes */
 int smk_last_frame_info(smk_ctx *ctx, int *kernel, float *ms, double *alg_bytes);
 /* HIP-event timing of the render kernel on its launch stream: reset, render N frames, read the
  * average (ms) over the last min(N,64) frames.  smk_timing_read synchronises the device. */
