@@ -70,30 +70,42 @@ __global__ __launch_bounds__(256) void smk_k_brick_minmax(const void *vox, int D
   if (lane == 0) mm[brick] = any_bad ? make_float4(1.0f, 0.0f, 1.0f, 0.0f) : make_float4(vmin, vmax, gmin, gmax);
 }
 
-// sat[(t + 1) * (sv + 1) + (s + 1)] = number of set bits (t', s') with t' <= t, s' <= s; one workgroup, a thread per
-// column: the bits of row t up to column s are popcounts of the row's words (read from an LDS copy of the bitmap when
-// it fits), so a thread's only serial chain is its running sum -- no load depends on a store
-__global__ __launch_bounds__(256) void smk_k_occ_sat(const uint32_t *occ, int roww, int sv, int sg, uint32_t *sat) {
-  extern __shared__ uint32_t bits[];
-  const int words = roww * sg;
-  const bool staged = words <= 12288;
-  if (staged) {
-    for (int i = threadIdx.x; i < words; i += 256) bits[i] = occ[i];
-    __syncthreads();
+// sat[(t + 1) * (sv + 1) + (s + 1)] = number of set bits (t', s') with t' <= t, s' <= s.  A wave per column s: the bits of
+// row t up to column s are popcounts of the row's words, each lane sums them over its run of consecutive rows, a wave
+// scan makes the runs' offsets, and a second pass over the same words writes the running sums -- no load depends on a
+// store, and sv + 1 waves share the work (the extra one clears row 0 and column 0).  (Rounds 2-3: ONE workgroup, a thread
+// per column walking all rows: 150 us for a 256 x 256 table -- longer than the frame of a 1/8 shard, whose camera moves.)
+__global__ __launch_bounds__(64) void smk_k_occ_sat(const uint32_t *occ, int roww, int sv, int sg, uint32_t *sat) {
+  const int s = blockIdx.x, lane = threadIdx.x, pitch = sv + 1;
+  if (s >= sv) {
+    for (int i = lane; i < pitch; i += 64) sat[i] = 0;
+    for (int t = lane; t < sg; t += 64) sat[(size_t)(t + 1) * pitch] = 0;
+    return;
   }
-  const uint32_t *src = staged ? bits : occ;
-  const int pitch = sv + 1;
-  for (int i = threadIdx.x; i < pitch; i += 256) sat[i] = 0;
-  for (int t = threadIdx.x; t < sg; t += 256) sat[(size_t)(t + 1) * pitch] = 0;
-  for (int s = threadIdx.x; s < sv; s += 256) {
-    const int w = s >> 5;
-    const uint32_t last = 0xffffffffu >> (31 - (s & 31));  // bits 0..s of word w
-    uint32_t run = 0;
-    for (int t = 0; t < sg; ++t) {
-      const uint32_t *row = src + (size_t)t * roww;
-      uint32_t n = __popc(row[w] & last);
-      for (int k = 0; k < w; ++k) n += __popc(row[k]);
-      run += n;
+  const int w = s >> 5;
+  const uint32_t last = 0xffffffffu >> (31 - (s & 31));  // bits 0..s of word w
+  const int R = (sg + 63) >> 6;                           // rows per lane: t = lane * R + r
+  auto row_bits = [&](int t) -> uint32_t {
+    const uint32_t *row = occ + (size_t)t * roww;
+    uint32_t n = __popc(row[w] & last);
+    for (int k = 0; k < w; ++k) n += __popc(row[k]);
+    return n;
+  };
+  uint32_t mine = 0;
+  for (int r = 0; r < R; ++r) {
+    const int t = lane * R + r;
+    if (t < sg) mine += row_bits(t);
+  }
+  uint32_t incl = mine;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  uint32_t run = incl - mine;
+  for (int r = 0; r < R; ++r) {
+    const int t = lane * R + r;
+    if (t < sg) {
+      run += row_bits(t);
       sat[(size_t)(t + 1) * pitch + s + 1] = run;
     }
   }
@@ -156,8 +168,7 @@ hipError_t smk_bricks_minmax(const void *vox, int dtype, const int D[3], const i
 hipError_t smk_bricks_flags(const float4 *mm, const int nb[3], const uint32_t *occ, int roww, int sv, int sg, uint32_t *sat,
                             unsigned char *flags, unsigned *count, hipStream_t s) {
   const long long nbricks = (long long)nb[0] * nb[1] * nb[2];
-  const size_t words = (size_t)roww * sg;
-  hipLaunchKernelGGL(smk_k_occ_sat, dim3(1), dim3(256), words <= 12288 ? words * 4 : 0, s, occ, roww, sv, sg, sat);
+  hipLaunchKernelGGL(smk_k_occ_sat, dim3((unsigned)sv + 1), dim3(64), 0, s, occ, roww, sv, sg, sat);
   hipError_t e = hipMemsetAsync(count, 0, 4, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(smk_k_brick_flags, dim3((unsigned)((nbricks + 255) / 256)), dim3(256), 0, s, mm, nbricks, sat, sv, sg, flags, count);
