@@ -422,7 +422,9 @@ __global__ __launch_bounds__(256) void smk_k_shadow_light_march(const RenderPara
   for (int kb = 1; kb < kb_first && kb <= sc.nslices; kb += 8)
     if (live && kb + sl <= sc.nslices) hist[(size_t)(kb + sl) * nl + o] = L;
   // Four turns' worth (32 slices) of positions and brick flags at a time: the flag loads are in flight together -- one round
-  // trip per 32 slices where a turn of its own costs one per 8 (the march is bound by such round trips: 1.0 -> x.xx ms)
+  // trip per 32 slices where a turn of its own costs one per 8.  (Measured: no gain, 1.00-1.03 ms either way -- the turns that
+  // cost are those with samples in flagged bricks, a chain of corner, occupancy and table round trips each; forcing 8 waves
+  // per SIMD to overlap more of them spills: 1.0 -> 1.45 ms.)
   int kb = kb_first;
   for (; kb <= sc.nslices && kb <= khi; kb += 32) {
     float pu[4][3];
