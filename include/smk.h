@@ -146,7 +146,8 @@ int smk_set_perturb(smk_ctx *ctx, const unsigned char *noise_rgba, int n, const 
  * ONE march per texel that keeps every slice's buffer (nslices + 1 buffers in device memory), and the eye pass is an
  * ordinary frame of the ray-marchers over the half-angle slices that looks each sample's slice up -- two launches instead
  * of one per slice.  Option "shadow_march" 0 (or a history that does not fit a quarter of the free device memory) renders
- * a launch per slice as the reference draws them: the same samples, bit-identical light buffers. */
+ * a launch per slice as the reference draws them: the same samples, bit-identical light buffers.  The light buffers belong
+ * to the context: its frames with shadows must be enqueued on ONE stream (they order themselves there). */
 int smk_set_shadow(smk_ctx *ctx, int on, int buffer_px, float quality);
 /* replaces the glBlendFunc / glBlendEquationEXT state of the slice loop (VolumeRenderer.cpp:589-590,
  * NV20VolRen3D.cpp:158-163, 930; R8kVolRen3D.cpp:1436-1449).  Default: front to back.  The two

@@ -277,7 +277,7 @@ struct smk_ctx {
   float shadow_q = .5f;
   float4 *d_light[2] = {nullptr, nullptr};  // ping-pong light buffers, light_cap texels each
   size_t light_cap = 0;
-  int light_final = 0, light_lb = 0;        // which one the last frame finished in, and its edge
+  int light_lb = 0;                         // the light buffer's edge in the last frame with shadows
   float4 *d_light_hist = nullptr;           // [nslices + 1][LB][LB]: every slice's light buffer (the two marches, smk_shadow.hip)
   size_t light_hist_cap = 0;                // texels
   const float4 *d_light_last = nullptr;     // the light buffer the last frame with shadows left (in d_light[] or the history)

@@ -1,18 +1,21 @@
-// smk_shadow.hip -- half-angle-slicing shadows: the eye pass and the light pass of a slice side by side in one grid; all
-// slices in ONE cooperative launch with a grid barrier between them (smk_k_shadow_fused), or a launch per slice.
+// smk_shadow.hip -- half-angle-slicing shadows.
 //
 // Replaces R8kVolRen3D's shadow mode: the slice axis half-way between view and light direction
 // (R8kVolRen3D.cpp:296-326), volShadow's two draws per slice polygon (:1651-1868: the slice into the
 // frame buffer with the light buffer bound as texture 5, then the same slice into the light buffer), the
-// light-buffer fragment shader (:2991-3180) and the eye shader's `1 - shadow` term (:2928-2934).  The
-// reference ping-pongs two pbuffers; so does this (the eye pass of slice k reads the buffer as slices
-// < k left it, the light pass writes the other one -- including the texels the slice does not cover,
-// which the reference leaves two slices stale).
+// light-buffer fragment shader (:2991-3180) and the eye shader's `1 - shadow` term (:2928-2934).
 //
-// The recurrence over slices is inherent (slice k's shading needs the light buffer after slice k-1 at
-// an arbitrary position), so the frame is S small launches instead of one march; each sample is a
-// gather of 8 voxels from HBM/L2 like kernel G's.  Sample placement: the fma chains of smk_shadowcoef,
-// evaluated identically by the CPU checker.
+// Three forms of the same arithmetic, sample placement by the fma chains of smk_shadowcoef /
+// SmkShadowRays, evaluated identically by the CPU checker:
+//   * the default (round 3): the LIGHT MARCH below -- a light-buffer texel depends on itself alone from slice to
+//     slice, so the light pass is one march per texel that keeps every slice's buffer -- and the eye pass as an
+//     ordinary frame of the ray-marchers (smk_slab.hip / smk_gather.hip, SHD instances) over the half-angle slices,
+//     which looks each sample's slice up (smk_shadow_term, smk_device.h).  Two launches.
+//   * a launch per slice (option shadow_march 0; rounds 1-2): the eye pass and the light pass of a slice side by
+//     side in one grid, the light buffer ping-ponging as the reference's two pbuffers do (the eye pass of slice k
+//     reads the buffer as slices < k left it, the light pass writes the other one -- including the texels the slice
+//     does not cover, which the reference leaves two slices stale).
+//   * all slices in ONE cooperative launch with a grid barrier between them (option shadow_fused; measured slower).
 #include <stdlib.h>
 #include <string.h>
 
