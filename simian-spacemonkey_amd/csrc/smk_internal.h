@@ -111,7 +111,7 @@ struct SlabAux {
   } scan[4];
   unsigned scan_next = 0;
   std::vector<unsigned char> shape_key;  // the small-workgroup shape chosen for this view class (see the launcher's probing pass)
-  int shape_choice = -1, shape_age = 0;
+  int shape_choice = -1, shape_age = 0, shape_chunks = 0;  // (... its age in frames, and the DMA chunks per slice it had when chosen)
   std::vector<int> plan_work;   // the weights the last schedule was built from,
   std::vector<unsigned char> plan_cuts;  // the cuts,
   std::vector<int2> plan_order;  // and that schedule

@@ -1916,7 +1916,7 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
   // (one loader wave moves ~10 B/cycle at best, MI355X_MICROARCH.md 'ldsdma-fill'; a heavy
   //  stream needs several per CU)
   struct Cfg { int tw, th, nl; };
-  Cfg cfgs[2] = {{32, 16, 2}, {32, 24, 4}};
+  Cfg cfgs[3] = {{32, 16, 2}, {32, 24, 4}, {32, 24, 4}};
   int ncfg = 2;
   if (opt_tile == 1) { cfgs[0] = {16, 16, 1}; ncfg = 1; }
   else if (opt_tile == 2) { cfgs[0] = {24, 32, 4}; ncfg = 1; }
@@ -1975,8 +1975,16 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
                            aux->shape_choice >= 0 && ++aux->shape_age < 64;
   if (shape_known) best = aux->shape_choice;
   for (int pass = (choose && !shape_known) ? 0 : 1; pass < 2; ++pass) {
+  int alt = -1;  // the other twelve-wave shape: tried before the big workgroup where the chosen one turns out not to fit
   if (pass == 1 && best >= 0) {
     cfgs[0] = cand[best];
+    // (the probe sizes windows from a sparse scan and can rank a shape by a window it will not get: near a pitch step the
+    //  real window of the narrow tile is half as big again, its ring no longer fits half a CU -- a turning camera then
+    //  rendered 60 frames in a row on the big workgroup, 0.72 ms, where the other small shape takes 0.63)
+    alt = best == 0 ? 1 : 0;
+    cfgs[1] = cand[alt];
+    cfgs[2] = {32, 24, 4};
+    ncfg = 3;
     if (!shape_known) {
       aux->shape_key.assign(reinterpret_cast<const unsigned char *>(&skey), reinterpret_cast<const unsigned char *>(&skey) + sizeof skey);
       aux->shape_choice = best;
@@ -2126,6 +2134,14 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     // small workgroups: a window of whole row groups (its LDS image is that big anyway), see the loader's group loop
     if ((nw + nl) <= SLAB_BIG_WAVES && Q.groups * Q.rpg <= Q.Dv) Q.wv = Q.groups * Q.rpg;
     Q.chunks = Q.groups * Q.per;
+    // (a kept shape is probed again the moment its own window changes size -- a narrow tile's window row crosses a pitch
+    //  step of 8 units within a degree or two of a turning camera, its DMA count jumps by half, its ring no longer fits
+    //  half a CU and the frames fall to the big workgroup: 0.72 ms where the other small shape takes 0.63 -- not only
+    //  every 64 frames)
+    if (pass == 1 && choose && best >= 0 && ci == 0) {
+      if (shape_known && aux->shape_chunks != Q.chunks) aux->shape_age = 64;
+      if (!shape_known) aux->shape_chunks = Q.chunks;
+    }
     if (pass == 0) {  // probing: DMA instructions per ray
       // (the ten-wave shape leaves four of a CU's wave slots idle: with the brick flags on it measures 0.83 ms on the cfg 3
       //  frame where the twelve-wave shapes take 0.59-0.61, although it needs the fewest DMA instructions per ray at some
@@ -2144,7 +2160,10 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     const int lpg = nl / nlg;
     if ((Q.groups + lpg - 1) / lpg * Q.per > 63) { if (ci + 1 < nlist) continue; *why = "window needs more than 63 DMA chunks per loader"; return hipErrorNotSupported; }
     // light enough for this configuration?  otherwise try the next (heavier-duty) one
-    if (ci + 1 < nlist && (double)Q.chunks * 1024.0 / (nw * 64) > 16.0 * nl) continue;
+    if (ci + 1 < nlist && (double)Q.chunks * 1024.0 / (nw * 64) > 16.0 * nl) {
+      if (pass == 1 && alt >= 0 && ci == 0) ci = 1;  // (a stream this heavy is too heavy for the other small shape as well: the big one next)
+      continue;
+    }
 
     Q.use_ah = (tf_mode == 1 && P.third_axis && P.nelts <= 3 && P.sv >= 2 && P.sv <= 2048) ? 1 : 0;
     if (tf_mode == 1 && (P.sv < 2 || P.sg < 2)) { *why = "transfer function smaller than 2x2"; return hipErrorNotSupported; }
@@ -2178,6 +2197,11 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     if (opt_ns >= 3 && ns > opt_ns) ns = opt_ns;  // (experiment knob: cap the ring)
     if (ns < 3) { if (ci + 1 < nlist) continue; *why = "window does not fit LDS"; return hipErrorNotSupported; }
     Q.nslots = ns;
+    if (pass == 1 && choose && alt >= 0 && ci == 1) {  // the alternative shape it is: kept from the next frame on
+      aux->shape_choice = alt;
+      aux->shape_chunks = Q.chunks;
+      aux->shape_age = 0;
+    }
     // (the set-up keeps a 16-byte brick mask per layer of bricks in the ring's memory before the stream starts)
     if (Q.bricks && (size_t)ns * Q.slot_bytes < ((size_t)((Q.Ds - 1) >> SMK_BRICK_LOG2) + 1) * 16) Q.bricks = nullptr;
     const int mych = (Q.groups + lpg - 1) / lpg * Q.per;  // most DMA instructions one loader issues per slice
