@@ -139,8 +139,10 @@ int smk_set_perturb(smk_ctx *ctx, const unsigned char *noise_rgba, int n, const 
  * :2991-3180) under the light's projection (LTWidgetRen::genXForm, LTWidgetRen.cpp:231-291).  Uses the
  * light position, eye, at and xform of smk_set_shading.  buffer_px = gluvv.light.buffsz[0], quality =
  * gluvv.light.gShadowQual or iShadowQual: the light buffer has ceil(quality * buffer_px)^2 texels.
- * Applies to 2-D / 3-D classification with no or R8k shading on an unsharded context; other
- * configurations make smk_render fail with the reason.  The blend order follows the light (under when
+ * Applies to 2-D / 3-D classification with no or R8k shading on an unsharded context, with or without the clip-plane
+ * widget's planes (smk_set_clip, smk_set_clip_plane: both passes leave out what lies beyond them, as the reference's
+ * clipped slice polygons do); other configurations (1-D table, NV20 combiners, perturbation, a sub-box, depth output,
+ * shards) make smk_render fail with the reason.  The blend order follows the light (under when
  * the slices run away from the eye, over otherwise), smk_set_blend is not consulted.
  * How it is rendered: a light-buffer texel depends on itself alone from slice to slice, so the light pass is
  * ONE march per texel that keeps every slice's buffer (nslices + 1 buffers in device memory), and the eye pass is an

@@ -444,21 +444,9 @@ void orc_clip_plane_voxel(const double plane_eye[4], const double mv[16], const 
   out[3] = (float)w;
 }
 
-/* ------------------------------------------------------------ one ray */
-
-static long long march_pixel(const orc_volume *v, const orc_classify *tf, const orc_shade *sh,
-                             const orc_perturb *pt, const orc_raycoef *rc, int blend, int i, int j,
-                             float out[4], float *depth, float znear) {
-  float px = fmaf((float)i + 0.5f, rc->pxs, rc->pxl);
-  float py = fmaf((float)j + 0.5f, rc->pys, rc->pyl);
-  float A[3], B[3];
-  for (int a = 0; a < 3; ++a) {
-    A[a] = fmaf(px, rc->Ax[a], fmaf(py, rc->Ay[a], rc->Ac[a]));
-    B[a] = fmaf(px, rc->Bx[a], fmaf(py, rc->By[a], rc->Bc[a]));
-  }
+/* the box samples must lie in: the region [g0, g1) in voxel coordinates, cut by the orthogonal clip plane */
+static void region_box(const orc_volume *v, float lo[3], float hi[3], int top[3]) {
   const int N[3] = {v->nx, v->ny, v->nz};
-  float lo[3], hi[3];
-  int top[3];
   for (int a = 0; a < 3; ++a) {
     lo[a] = (float)v->g0[a] - 0.5f;
     hi[a] = (float)v->g1[a] - 0.5f;
@@ -480,6 +468,23 @@ static long long march_pixel(const orc_volume *v, const orc_classify *tf, const 
       lo[a] = face;
     }
   }
+}
+
+/* ------------------------------------------------------------ one ray */
+
+static long long march_pixel(const orc_volume *v, const orc_classify *tf, const orc_shade *sh,
+                             const orc_perturb *pt, const orc_raycoef *rc, int blend, int i, int j,
+                             float out[4], float *depth, float znear) {
+  float px = fmaf((float)i + 0.5f, rc->pxs, rc->pxl);
+  float py = fmaf((float)j + 0.5f, rc->pys, rc->pyl);
+  float A[3], B[3];
+  for (int a = 0; a < 3; ++a) {
+    A[a] = fmaf(px, rc->Ax[a], fmaf(py, rc->Ay[a], rc->Ac[a]));
+    B[a] = fmaf(px, rc->Bx[a], fmaf(py, rc->By[a], rc->Bc[a]));
+  }
+  float lo[3], hi[3];
+  int top[3];
+  region_box(v, lo, hi, top);
   float C[4] = {0, 0, 0, 0};
   float first = INFINITY;
   long long inside = 0;
@@ -727,7 +732,11 @@ int orc_render_shadow(const orc_volume *v, const orc_classify *tf, const orc_cam
                       const orc_shadowcoef *sc, float *rgba, float *light_out, int nthreads) {
   if (tf->mode == ORC_TF_1D || (sh && sh->mode == ORC_SHADE_NV20)) return 2;
   const int W = cam->width, H = cam->height, LB = sc->LB;
-  const int N[3] = {v->nx, v->ny, v->nz};
+  /* the box both passes sample in: the volume, or what an orthogonal clip plane leaves of it (both passes draw the same
+   * clipped slice polygons, and glClipPlane stays enabled through both); closed */
+  float blo[3], bhi[3];
+  int btop[3];
+  region_box(v, blo, bhi, btop);
   float *L0 = (float *)calloc((size_t)LB * LB * 4, sizeof(float));
   float *L1 = (float *)calloc((size_t)LB * LB * 4, sizeof(float));
   if (!L0 || !L1) { free(L0); free(L1); return 1; }
@@ -765,9 +774,10 @@ int orc_render_shadow(const orc_volume *v, const orc_classify *tf, const orc_cam
           const float A = fmaf(tauA, D, sc->Ec[a]), B = dtau * D;
           p[a] = fmaf((float)m, B, A);
           /* (the box 2^-10 voxels wide: the last slice lies ON the far corner / face, where the chain's rounding would decide) */
-          if (!(p[a] >= -0.5f - 0.0009765625f && p[a] <= (float)N[a] - 0.5f + 0.0009765625f)) in = 0;
+          if (!(p[a] >= blo[a] - 0.0009765625f && p[a] <= bhi[a] + 0.0009765625f)) in = 0;
         }
         if (!in) continue;
+        if (v->cplane_on && !(fmaf(p[0], v->cplane[0], fmaf(p[1], v->cplane[1], fmaf(p[2], v->cplane[2], v->cplane[3]))) >= 0.0f)) continue;
         float *C = rgba + 4 * ((size_t)j * W + i);
         if (sc->front_to_back && C[3] == 1.0f) continue;   /* (no later sample can change the pixel) */
         const float lw = fmaf(p[0], sc->Wm[0], fmaf(p[1], sc->Wm[1], fmaf(p[2], sc->Wm[2], sc->Wm[3])));
@@ -803,9 +813,10 @@ int orc_render_shadow(const orc_volume *v, const orc_classify *tf, const orc_cam
         for (int q = 0; q < 3; ++q) {
           const float G = fmaf(a, sc->Gx[q], fmaf(b, sc->Gy[q], sc->Gc[q]));
           p[q] = fmaf(w, G, sc->Lc[q]);
-          if (!(p[q] >= -0.5f && p[q] <= (float)N[q] - 0.5f)) in = 0;
+          if (!(p[q] >= blo[q] && p[q] <= bhi[q])) in = 0;
         }
         if (!in) continue;
+        if (v->cplane_on && !(fmaf(p[0], v->cplane[0], fmaf(p[1], v->cplane[1], fmaf(p[2], v->cplane[2], v->cplane[3]))) >= 0.0f)) continue;
         float col[4];
         if (!classify_sample(v, tf, p[0], p[1], p[2], col)) continue;
         for (int q = 0; q < 3; ++q) Ln[q] = sat(fmaf(col[3], sat(col[q]) - Lo[q], Lo[q]));

@@ -1717,8 +1717,8 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
     if (c->tf_mode == 0) FAIL(c, "smk_render: shadows need a 2-D or 3-D transfer function (the 1-D table renderer has no shadow mode)");
     if (sk == 2) FAIL(c, "smk_render: shadows are implemented for R8k shading or none (NV20 combiners: no shadow mode in NV20VolRen3D)");
     if (c->nranks > 1) FAIL(c, "smk_render: shadows need the whole volume on one GPU (the light buffer couples every slice of every brick)");
-    if (P.pert_on || c->cplane_on || c->clip_axis || d_depth)
-      FAIL(c, "smk_render: shadows cannot be combined with perturbation, clip planes or depth output");
+    if (P.pert_on || d_depth || c->region_on)
+      FAIL(c, "smk_render: shadows cannot be combined with perturbation, a sub-box or depth output");
     if (c->opt_kernel == 3) FAIL(c, "smk_render: the column-stream kernel has no shadow mode");
     smk_shadowcoef sc;
     if (compute_shadowcoef(c, &sc)) return 1;
@@ -1746,9 +1746,14 @@ extern "C" int smk_render_device(smk_ctx *c, void *d_rgba, void *d_depth, void *
     // the eye) -- where a sample's coordinate, the end of an fma chain, lands on either side of the face by rounding.  The
     // reference draws that slice (a polygon clipped against the box keeps its boundary); the eye pass's membership test is
     // therefore 2^-10 voxels wide of the box (clamp-to-edge fetches: the value at the face).  The CPU checker does the same.
+    // Clip planes (round 3): both passes draw the same clipped slice polygons in the reference (volShadow slices the box
+    // setupClips left; glClipPlane stays enabled), so a light ray's sample must lie in the same box (closed, no slack: its
+    // last slice gets no special treatment in rounds 1-2 either) and on the kept side of the free plane.
     for (int a = 0; a < 3; ++a) {
-      P.lo[a] = -0.5f - SMK_SHADOW_BOX_EPS;
-      P.hi[a] = (float)c->N[a] - 0.5f + SMK_SHADOW_BOX_EPS;
+      h.llo[a] = P.lo[a];
+      h.lhi[a] = P.hi[a];
+      P.lo[a] -= SMK_SHADOW_BOX_EPS;
+      P.hi[a] += SMK_SHADOW_BOX_EPS;
       P.hin[a] = P.hi[a];
       P.top[a] = 1;
     }

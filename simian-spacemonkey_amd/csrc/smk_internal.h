@@ -28,6 +28,7 @@ struct SmkShadowRays {
   int on;  // 0: the affine coefficients of smk_raycoef
   float Ec[3], Dc[3], Dx[3], Dy[3], nDc, nDx, nDy;
   float numA, dB;
+  float llo[3], lhi[3];  // the box a LIGHT ray's sample must lie in (closed): the volume, or what an orthogonal clip plane leaves of it
   int k0, dk, LB;
   float Xm[4], Ym[4], Wm[4], lscale, lbias;
   const float4 *hist;  // [nslices + 1] buffers of [LB][LB] texels, `hstride` texels apart

@@ -171,6 +171,7 @@ __device__ __forceinline__ void shadow_eye_pixel(const RenderParams &P, const Sh
     in = in && p[a] >= P.lo[a] && p[a] <= P.hi[a];  // (the box, 2^-10 voxels wide: smk_api.hip)
   }
   if (!in) return;
+  if (P.cplane_on && !(__fmaf_rn(p[0], P.cplane[0], __fmaf_rn(p[1], P.cplane[1], __fmaf_rn(p[2], P.cplane[2], P.cplane[3]))) >= 0.0f)) return;
   const size_t o = (size_t)j * P.W + i;
   float4 C = shadow_ld4<COH>(P.out + o);
   if (sc.front_to_back && C.w == 1.0f) return;  // exact: every later weight (1-A) is 0
@@ -222,8 +223,9 @@ __device__ __forceinline__ void shadow_light_texel(const RenderParams &P, const 
   for (int q = 0; q < 3; ++q) {
     const float G = __fmaf_rn(a, sc.Gx[q], __fmaf_rn(bb, sc.Gy[q], sc.Gc[q]));
     p[q] = __fmaf_rn(w, G, sc.Lc[q]);
-    in = in && p[q] >= -0.5f && p[q] <= (float)P.N[q] - 0.5f;
+    in = in && p[q] >= P.sh.llo[q] && p[q] <= P.sh.lhi[q];
   }
+  if (in && P.cplane_on) in = __fmaf_rn(p[0], P.cplane[0], __fmaf_rn(p[1], P.cplane[1], __fmaf_rn(p[2], P.cplane[2], P.cplane[3]))) >= 0.0f;
   if (in && !shadow_brick_empty(P, p[0], p[1], p[2])) {
     float ch0, ch1, ch2, ch3, n0, n1, n2;
     shadow_fetch<DT, TF, false>(P, p[0], p[1], p[2], ch0, ch1, ch2, ch3, n0, n1, n2);
@@ -320,7 +322,7 @@ __device__ __forceinline__ void shadow_k_range(const RenderParams &P, float num0
   float ta = 0.0f, tb = __int_as_float(0x7f800000);
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
-    const float lo = -0.55f, hi = (float)P.N[a] - 0.45f;
+    const float lo = P.sh.llo[a] - 0.05f, hi = P.sh.lhi[a] + 0.05f;
     if (fabsf(D[a]) > 1e-20f) {
       const float inv = 1.0f / D[a];
       const float t1 = (lo - E[a]) * inv, t2 = (hi - E[a]) * inv;
@@ -400,8 +402,9 @@ __global__ __launch_bounds__(256) void smk_k_shadow_light_march(const RenderPara
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       p[q] = __fmaf_rn(w, G[q], sc.Lc[q]);
-      in = in && p[q] >= -0.5f && p[q] <= (float)P.N[q] - 0.5f;
+      in = in && p[q] >= P.sh.llo[q] && p[q] <= P.sh.lhi[q];
     }
+    if (in && P.cplane_on) in = __fmaf_rn(p[0], P.cplane[0], __fmaf_rn(p[1], P.cplane[1], __fmaf_rn(p[2], P.cplane[2], P.cplane[3]))) >= 0.0f;
     return in;
   };
   auto flag_of = [&](bool in) -> unsigned char {

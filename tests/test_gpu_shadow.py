@@ -183,3 +183,46 @@ def test_two_marches_equal_a_launch_per_slice(R, light, kind, f32, shade, pose):
             assert np.array_equal(out[kern][0], b)
         else:
             assert np.abs(out[kern][0] - b).max() <= 2e-5
+
+
+@pytest.mark.parametrize("light", ["oblique", "behind"])
+@pytest.mark.parametrize("which", ["orthogonal", "free", "both"])
+def test_shadows_with_clip_planes(R, which, light):
+    """Round 3: frames with shadows take the clip-plane widget's planes.  The reference draws the same clipped slice
+    polygons in both passes (volShadow slices the box setupClips left, NV20VolRen3D.cpp:251-327; glClipPlane stays
+    enabled, :346-357), so neither the eye nor the light pass has a sample beyond a plane: frame and light buffer against
+    the CPU checker, the two ray-marchers bit for bit, and the two marches against a launch per slice."""
+    sc = make_scene("cfg3", n=48, size=112, steps=150, f32=True, shade=1, pose="rot")
+    sc.light_pos = LIGHTS[light]
+    sc.shadow = (96, 0.7)
+    if which in ("orthogonal", "both"):
+        sc.clip = (3, tuple(0.55 * float(f) for f in sc.fsize))      # Y+: what lies below y = .55 stays
+    if which in ("free", "both"):
+        n = np.array([0.35, -0.2, -0.9])
+        n /= np.linalg.norm(n)
+        mv = np.array(sc.mv(), np.float64).reshape(4, 4).T
+        centre = mv @ np.array([float(sc.fsize[0]) / 2, float(sc.fsize[1]) / 2, float(sc.fsize[2]) / 2, 1.0])
+        sc.clip_plane = (n[0], n[1], n[2], -float(n @ centre[:3]) + 0.03)
+    try:
+        ref, _ = _check(R, sc)
+        unclipped = make_scene("cfg3", n=48, size=112, steps=150, f32=True, shade=1, pose="rot")
+        unclipped.light_pos, unclipped.shadow = sc.light_pos, sc.shadow
+        full, _ = unclipped.render_shadow()
+        assert np.abs(full - ref).max() > 1e-2              # (the planes do cut something)
+        f2b = R.shadowcoef().front_to_back
+        out = {}
+        for kern in (1, 2):
+            R.set_option("kernel", kern)
+            out[kern] = (R.render(), R.light_buffer())
+            assert R.last_frame_info()[0] == kern
+        R.set_option("kernel", 0)
+        R.set_option("shadow_march", 0)
+        b, lb = R.render(), R.light_buffer()
+        assert np.array_equal(out[1][0], out[2][0]) and np.array_equal(out[1][1], lb) and np.array_equal(out[2][1], lb)
+        assert np.array_equal(out[2][0], b) if f2b else np.abs(out[2][0] - b).max() <= 2e-5
+    finally:
+        R.set_option("shadow_march", 1)
+        R.set_option("kernel", 0)
+        sc.clip = None
+        sc.clip_plane = None
+        push_scene(R, sc)
