@@ -2123,12 +2123,28 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     Q.wv = Wv;
     if (Q.wu > 64) { if (ci + 1 < nlist || pass == 0) continue; *why = "window wider than one DMA chunk"; return hipErrorNotSupported; }
     if (Q.Du > 2047 || Q.Dv > 2047) { *why = "stored box wider than 2047 voxels across the view"; return hipErrorNotSupported; }
-    Q.wp = (Q.wu + 7) & ~7;
+    // The pitch: the next multiple of 8 units -- or, where that gives fewer DMA instructions per slice, the next multiple
+    // of 4 whose period is one the loaders know (per = 1, 3, 5, 7: pitches 12, 20, 28): a 17-unit row on a pitch of 20
+    // (two groups of 16 rows x 5 chunks) instead of 24 (four groups of 8 rows x 3 chunks) is 10 instructions for 12, and a
+    // ring that fits half a CU again.
     {
-      int g = 64, r = Q.wp;
-      while (r) { int t = g % r; g = r; r = t; }  // gcd(64, wp)
-      Q.per = Q.wp / g;
-      Q.rpg = 64 / g;
+      auto shape = [&](int wp, int &per, int &rpg, int &groups) {
+        int g = 64, r = wp;
+        while (r) { int t = g % r; g = r; r = t; }  // gcd(64, wp)
+        per = wp / g;
+        rpg = 64 / g;
+        groups = (Q.wv + rpg - 1) / rpg;
+      };
+      int wp8 = (Q.wu + 7) & ~7, per8, rpg8, gr8;
+      shape(wp8, per8, rpg8, gr8);
+      Q.wp = wp8; Q.per = per8; Q.rpg = rpg8;
+      const int wp4 = (Q.wu + 3) & ~3;
+      static const bool only8 = getenv("SMK_PITCH8") != nullptr;  // (developer: the pitches of rounds 1-3, multiples of 8)
+      if (wp4 != wp8 && !only8) {
+        int per4, rpg4, gr4;
+        shape(wp4, per4, rpg4, gr4);
+        if (per4 <= 7 && gr4 * per4 < gr8 * per8) { Q.wp = wp4; Q.per = per4; Q.rpg = rpg4; }
+      }
     }
     Q.groups = (Q.wv + Q.rpg - 1) / Q.rpg;
     // small workgroups: a window of whole row groups (its LDS image is that big anyway), see the loader's group loop
