@@ -163,7 +163,9 @@ int smk_set_blend(smk_ctx *ctx, smk_blend mode);
  * row 0 = bottom (GL window order).  depth_out (may be NULL): view-space depth of the first
  * contributing sample, +inf where none. */
 int smk_render(smk_ctx *ctx, float *rgba_out, float *depth_out);
-/* same with DEVICE output pointers; asynchronous on `stream` (a hipStream_t, NULL = default) */
+/* same with DEVICE output pointers; asynchronous on `stream` (a hipStream_t, NULL = default).  (Option "kernel" 0: the
+ * first nine frames of a configuration the context has not measured yet are trials of the two ray-marchers -- identical
+ * frames -- and six of them wait for the frame before them on `stream`: a one-time stall per configuration.) */
 int smk_render_device(smk_ctx *ctx, void *d_rgba, void *d_depth, void *stream);
 
 /* replaces VolumeRenderer::renderSlice(quad, alpha) (VolumeRenderer.h:114, VolumeRenderer.cpp:748-807): ONE quad (model
