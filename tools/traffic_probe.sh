@@ -1,3 +1,7 @@
+#!/bin/bash
+# Developer tool (GPU box, through gpurun from the repo root): HBM-side FETCH_SIZE (KiB as reported; bytes = 2 x 1024 x that
+# on gfx950) and the frame time of the slice-ring kernel on the four headline frames -- cfg 3 and the 1024^3 north star,
+# brick flags on and off.   gpurun -- bash tools/traffic_probe.sh
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 for cfg in "512 cfg3 kernel=2" "512 cfg3 kernel=2,bricks=0" "1024 cfg4 kernel=2" "1024 cfg4 kernel=2,bricks=0"; do
