@@ -200,3 +200,41 @@ def test_full_size_cfg5_multi_field_perturbed(gpu_renderer_factory, O, weights, 
     finally:
         for r in rs:
             r.close()
+
+
+def test_full_size_shadows_two_marches_equal_a_launch_per_slice(gpu_renderer_factory):
+    """BASELINE config 3 at full size with the shadow check box on (512 half-angle slices, 512^2 light buffer, the light
+    up-left of the eye: the slices run away from the viewer): the light march + the eye pass on either ray-marcher give the
+    frame and the light buffer of 512 per-slice launches, bit for bit (the same operations per pixel and texel in the same
+    order; the small-scene tests compare both forms with the CPU checker)."""
+    b = _bench()
+    n, size, planes = 512, 1024, 512
+    r = gpu_renderer_factory()
+    try:
+        vghf, nrm = b.make_volume(r, n)
+        r.upload_volume_device(vghf.data_ptr(), (n, n, n), 3, 1, nrm.data_ptr())
+        del vghf, nrm
+        xform, _ = b.configure(r, "cfg3", n, size, planes)
+        r.set_shading("r8k", (3.0, 4.0, -3.0), b.EYE, b.AT, [float(v) for v in xform.T.reshape(-1)], b.INTENS)
+        r.set_shadow(1, 1024, 0.5)
+        assert r.shadowcoef().front_to_back == 1
+        s = _frame(r, size, 2)
+        ls = r.light_buffer()
+        g = _frame(r, size, 1)
+        lg = r.light_buffer()
+        r.set_option("shadow_march", 0)
+        import torch
+        out = torch.zeros((size * size, 4), dtype=torch.float32, device="cuda")
+        r.set_option("kernel", 0)
+        r.render_device(out.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        assert r.last_frame_info()[0] == 3
+        p = out.cpu().numpy().reshape(size, size, 4)
+        lp = r.light_buffer()
+        assert p[..., 3].max() > 0.5 and lp[..., 3].max() > 0.5
+        assert np.array_equal(s, g) and np.array_equal(s, p)
+        assert np.array_equal(ls, lp) and np.array_equal(lg, lp)
+    finally:
+        r.set_option("shadow_march", 1)
+        r.set_shadow(0)
+        r.close()
