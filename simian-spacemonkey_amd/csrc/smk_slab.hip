@@ -1959,7 +1959,10 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     bool on; double t0; double *acc; decltype(dbg_now) *now;
     ~DbgExit() { if (on) *acc += (*now)() - t0; }
   } dbg_exit{dbg_time, dbg_t0, &dbg_t[2], &dbg_now};
-  Cfg cand[3] = {{16, 40, 2}, {40, 16, 2}, {32, 16, 2}};
+  // (the wide shape first: it wins a tie -- same DMA count, but its rows are twice as long; A/B on the cfg 3 frame turned
+  //  25 / 30 / 33 / 36 / 40 degrees, five alternations each: 0.611 / 0.577 / 0.614 / 0.636 / 0.625 ms against the narrow
+  //  shape's 0.606 / 0.614 / 0.627 / 0.654 / 0.641, tools/shape_ab.py)
+  Cfg cand[3] = {{40, 16, 2}, {16, 40, 2}, {32, 16, 2}};
   const bool choose = opt_tile == 0 && SLAB_BIG_WAVES >= 12;
   int best = -1;
   double best_score = 1e300;
