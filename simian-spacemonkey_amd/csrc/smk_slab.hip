@@ -1959,12 +1959,12 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
     bool on; double t0; double *acc; decltype(dbg_now) *now;
     ~DbgExit() { if (on) *acc += (*now)() - t0; }
   } dbg_exit{dbg_time, dbg_t0, &dbg_t[2], &dbg_now};
-  // (the wide shape first: it wins a tie -- same DMA count, but its rows are twice as long; A/B on the cfg 3 frame turned
+  // (a tie is won by the shape with the longer window rows, see the probe: same DMA count, rows twice as long; A/B on the cfg 3 frame turned
   //  25 / 30 / 33 / 36 / 40 degrees, five alternations each: 0.611 / 0.577 / 0.614 / 0.636 / 0.625 ms against the narrow
   //  shape's 0.606 / 0.614 / 0.627 / 0.654 / 0.641, tools/shape_ab.py)
   Cfg cand[3] = {{40, 16, 2}, {16, 40, 2}, {32, 16, 2}};
   const bool choose = opt_tile == 0 && SLAB_BIG_WAVES >= 12;
-  int best = -1;
+  int best = -1, best_wu = 0;
   double best_score = 1e300;
   // The choice is kept while the view keeps its principal axis, direction and sizes (re-examined every 64 frames): a
   // camera that moves every frame must not pay the probe -- nor flip between two shapes of nearly equal score, which
@@ -2166,7 +2166,10 @@ hipError_t smk_launch_slab(RenderParams P, int dtype, int tf_mode, int shade_kin
       //  frame where the twelve-wave shapes take 0.59-0.61, although it needs the fewest DMA instructions per ray at some
       //  poses -- a camera turning through such a pose got 0.79 ms frames for 0.63.  It has to win by 40 % now.)
       const double score = (double)Q.chunks / (nw * 64) * (nw + nl < 12 ? 1.4 : 1.0);
-      if (score < best_score) { best_score = score; best = ci; }
+      // (a tie goes to the shape with the LONGER window rows -- the same DMA count in fewer, longer runs of memory: on the
+      //  cfg 3 frame the wide shape, whose rows lie along the image's x there; a view turned a quarter about its axis has
+      //  them along y)
+      if (score < best_score || (score == best_score && Q.wu > best_wu)) { best_score = score; best = ci; best_wu = Q.wu; }
       continue;
     }
     Q.slot_bytes = Q.chunks * 1024;
